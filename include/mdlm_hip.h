@@ -1,0 +1,187 @@
+/* mdlm_hip.h -- C-ABI of libmdlm_hip.so: MI355X (gfx950) kernels for the MDLM
+ * denoise-and-sample hot path.
+ *
+ * Every entry point takes raw DEVICE pointers + sizes + a hipStream_t (passed
+ * as void*), launches asynchronously on that stream, allocates nothing, keeps
+ * no pointer after return and returns int: 0 = OK, <0 = argument error
+ * (message via mdlm_last_error_string(), thread-local), >0 = hipError_t.
+ * Token ids are int64, activations fp32 or bf16 (MDLM_F32 / MDLM_BF16), all
+ * matrices row-major with the innermost dimension contiguous and an explicit
+ * leading dimension `ld` (in ELEMENTS) where noted.
+ *
+ * Each declaration cites the reference code (kuleshov-group/mdlm) it replaces.
+ */
+#ifndef MDLM_HIP_H
+#define MDLM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDLM_F32 0
+#define MDLM_BF16 1
+
+/* GEMM epilogues (mdlm_gemm_bf16) */
+#define MDLM_EPI_STORE 0          /* C = acc (+bias)                       */
+#define MDLM_EPI_BIAS_GELU 1      /* C = gelu_tanh(acc + bias)             */
+#define MDLM_EPI_GATE_RESIDUAL 2  /* C = residual + gate * (acc (+bias))   */
+#define MDLM_EPI_QKV_ROTARY 3     /* q,k rotary -> head-major; v -> v^T    */
+
+int mdlm_version(void);
+const char* mdlm_last_error_string(void);
+
+/* ---------------------------------------------------------------- sampler */
+
+/* (a) Diffusion._subs_parameterization, diffusion.py:261-277.
+ * logits (rows, V) with leading dim ld_in -> log-probs (rows, V), ld_out.
+ * Masked rows (xt == mask_index): logit - logsumexp with the mask column
+ * shifted by -1e6; other rows: -1e6 everywhere, 0 at xt.  `logits` is not
+ * modified (the reference mutates its mask column in place; callers that
+ * rely on that see the same values through the returned tensor). */
+int mdlm_subs_logprobs(const void* logits, int64_t ld_in, int dtype_in,
+                       const int64_t* xt, void* out, int64_t ld_out,
+                       int dtype_out, int64_t rows, int V, int mask_index,
+                       void* stream);
+
+/* Row log-sum-exp of the SUBS-shifted logits (diffusion.py:263-268) for the
+ * masked rows only; rows with xt != mask get lse = 0 and are not read. */
+int mdlm_subs_row_lse(const void* logits, int64_t ld, int dtype,
+                      const int64_t* xt, float* lse, int64_t rows, int V,
+                      int mask_index, void* stream);
+
+/* (a') noise removal: argmax_v SUBS(logits), diffusion.py:690-697 / 982.
+ * Unmasked rows return xt; masked rows the best non-mask column (first index
+ * on ties). */
+int mdlm_subs_argmax(const void* logits, int64_t ld, int dtype,
+                     const int64_t* xt, int64_t* out, int64_t rows, int V,
+                     int mask_index, void* stream);
+
+/* (b) Diffusion._ddpm_caching_update with a cached p_x0, diffusion.py:592-610
+ * + _sample_categorical, diffusion.py:24-28.
+ *   q = p_x0 * (t - (t - dt)); q[mask] = t - dt (fp32, in that order);
+ *   x_s = argmax_v q_v / (1e-10 - log(u_v + 1e-10)); carry-over of unmasked.
+ * p_x0 (B*L, V) probabilities, ld elements per row.  t (B) fp32.  u: (B*L, V)
+ * contiguous fp32 uniforms, or NULL to draw in-kernel (Philox4x32-10 keyed by
+ * seed; element (row, v) uses counter offset + row*ceil(V/4) + v/4, lane v%4 --
+ * the same stream mdlm_philox_uniform writes).  changed (B) int32, may be
+ * NULL: set to 1 when any token of the sample changed, else 0 (replaces the
+ * host-side torch.allclose of diffusion.py:682).  fast_math != 0 selects the
+ * hardware log/rcp approximations (throughput mode; not bit-exact). */
+int mdlm_ddpm_cache_update(const void* p_x0, int64_t ld, int dtype,
+                           const int64_t* x, const float* t, double dt,
+                           const float* u, uint64_t seed, uint64_t offset,
+                           int64_t* x_next, int32_t* changed, int B, int L,
+                           int V, int mask_index, int fast_math, void* stream);
+
+/* (a)+(b) fused from cached LOGITS: p_x0 = exp(logit - lse) is formed in
+ * registers (diffusion.py:602 `.exp()` + 261-277), never written.  lse (B*L)
+ * from mdlm_subs_row_lse.  Same sampling semantics as above. */
+int mdlm_subs_ddpm_update(const void* logits, int64_t ld, int dtype,
+                          const float* lse, const int64_t* x, const float* t,
+                          double dt, const float* u, uint64_t seed,
+                          uint64_t offset, int64_t* x_next, int32_t* changed,
+                          int B, int L, int V, int mask_index, int fast_math,
+                          void* stream);
+
+/* The uniforms the in-kernel generator uses, materialised (rows, V) fp32, so
+ * that tests can feed the oracle the same draw.  Test/diagnostic helper; no
+ * reference counterpart (the reference calls torch.rand_like, diffusion.py:27). */
+int mdlm_philox_uniform(float* out, int64_t rows, int V, uint64_t seed,
+                        uint64_t offset, void* stream);
+
+/* (c1) Diffusion.q_xt, diffusion.py:575-586: xt = mask where u < move_chance.
+ * move_chance (B) fp32; u (B, L) fp32 or NULL for in-kernel Philox (element i
+ * uses counter offset + i/4, lane i%4). */
+int mdlm_q_xt(const int64_t* x0, const float* move_chance, const float* u,
+              uint64_t seed, uint64_t offset, int64_t* xt, int B, int L,
+              int mask_index, void* stream);
+
+/* (c2) SUBS + gather + NELBO weight, diffusion.py:884-894 and 908:
+ *   nll[b,l] = -log p_theta(x0[b,l] | xt) * weight[b] * attn_mask[b,l]
+ * with weight = dsigma/expm1(sigma) supplied per sample; log-probs are never
+ * materialised.  attn_mask may be NULL (= ones). */
+int mdlm_subs_nll(const void* logits, int64_t ld, int dtype, const int64_t* xt,
+                  const int64_t* x0, const float* weight,
+                  const float* attn_mask, float* nll, int B, int L, int V,
+                  int mask_index, void* stream);
+
+/* fp64 metric sums, diffusion.py:44-65,369-376 (MeanMetric in float64):
+ * sums[0] += sum(nll), sums[1] += sum(attn_mask) (or n if NULL).  One
+ * workgroup, fixed order: deterministic. */
+int mdlm_nll_sums(const float* nll, const float* attn_mask, double* sums,
+                  int64_t n, void* stream);
+
+/* ------------------------------------------------------------ DiT backbone */
+
+/* EmbeddingLayer.forward, dit.py:298-299: out[r,:] = table[idx[src(r)],:] (fp32).
+ * sample_map (int32) may be NULL (src(r) = r); otherwise output row r belongs
+ * to compacted sample r / L and reads idx[sample_map[r / L] * L + r % L]
+ * (gathers the rows of the active samples).  n_rows_dev, if not NULL, is a
+ * device int32 holding how many of n_rows are live. */
+int mdlm_embed_rows(const float* table, const int64_t* idx,
+                    const int32_t* sample_map, int L, float* out,
+                    int64_t n_rows, int D, int vocab,
+                    const int32_t* n_rows_dev, void* stream);
+
+/* TimestepEmbedder.timestep_embedding, dit.py:162-184: (B) -> (B, dim). */
+int mdlm_timestep_embedding(const float* t, float* out, int B, int dim,
+                            void* stream);
+
+/* Small fp32 linear for the conditioning path (sigma_map MLP dit.py:186-189,
+ * adaLN_modulation dit.py:249-250, 318): out[b,n] = act_out(sum_k
+ * act_in(in[b,k]) * W[n,k] + bias[n]); act: 0 none, 1 SiLU. */
+int mdlm_linear_f32(const float* in, const float* W, const float* bias,
+                    float* out, int B, int N, int K, int act_in, int act_out,
+                    void* stream);
+
+/* LayerNorm (no affine, eps 1e-5, fp32) * weight, then modulate_fused,
+ * dit.py:126-134 + 74-78: out = LN(x)*w*(1+scale)+shift -> bf16.
+ * shift/scale (n_mod, D) fp32; row r uses modulation row (r / rows_per_mod)
+ * % n_mod (n_mod == 1: batch-invariant conditioning). */
+int mdlm_ln_modulate(const float* x, const float* ln_w, const float* shift,
+                     const float* scale, void* out_bf16, int64_t rows, int D,
+                     int64_t rows_per_mod, int n_mod,
+                     const int32_t* n_rows_dev, void* stream);
+
+/* nn.Linear on bf16 MFMA, dit.py:220-228, 256, 277, 306/320:
+ * C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  A bf16 (lda), W bf16 contiguous.
+ * Requires K % 64 == 0, M % 128 == 0.  bias (N) fp32 or NULL.
+ *   STORE          : C (ldc, dtype_c) = acc + bias
+ *   BIAS_GELU      : C bf16 = gelu_tanh(acc + bias)            (dit.py:225-228)
+ *   GATE_RESIDUAL  : C fp32 = residual + gate[row/rows_per_mod] * (acc + bias)
+ *                    (bias_dropout_add_scale, eval mode, dit.py:20-34)
+ *   QKV_ROTARY     : N = 3*H*64; q,k get the NeoX rotary (dit.py:112-115) with
+ *                    rot_cos/rot_sin (L,32) fp32 and are written head-major
+ *                    q[b,h,l,64], k[b,h,l,64]; v is written transposed
+ *                    vt[b,h,64,l]; C = base of a buffer of 3*M*H*64 bf16
+ *                    (q | k | vt).  rows_per_mod = L.
+ * m_rows_dev: optional device int32 with the number of live rows (tiles
+ * beyond it exit), so a fixed launch can serve a device-side active count. */
+int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
+                   void* C, int64_t ldc, int dtype_c, int64_t M, int N, int K,
+                   int epilogue, const float* gate, const float* residual,
+                   int64_t rows_per_mod, int n_mod, const float* rot_cos,
+                   const float* rot_sin, int n_heads,
+                   const int32_t* m_rows_dev, void* stream);
+
+/* Bidirectional attention, dit.py:265-275 (flash_attn_varlen_qkvpacked_func,
+ * equal lengths, no dropout, softmax scale 1/sqrt(64)): q,k (n_seq,H,L,64)
+ * bf16, vt (n_seq,H,64,L) bf16 -> out (n_seq*L, H*64) bf16.  L % 64 == 0. */
+int mdlm_attn_fwd(const void* q, const void* k, const void* vt, void* out,
+                  int n_seq, int H, int L, const int32_t* n_seq_dev,
+                  void* stream);
+
+/* ------------------------------------------------------- sampler plumbing */
+
+/* Build the active-sample list from per-sample `changed` flags (device side
+ * replacement for the host decision at diffusion.py:682-685): active[0..n)
+ * = ascending sample ids with changed != 0, *n_active = n, n_rows = n*L. */
+int mdlm_compact_active(const int32_t* changed, int32_t* active,
+                        int32_t* n_active, int32_t* n_rows, int B, int L,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,85 @@
+"""ctypes binding of libmdlm_hip.so (the C-ABI declared in include/mdlm_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  Build with `python __graft_entry__.py build` (or
+`make -C mdlm_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmdlm_hip.so')
+
+F32, BF16 = 0, 1
+EPI_STORE, EPI_BIAS_GELU, EPI_GATE_RESIDUAL, EPI_QKV_ROTARY = 0, 1, 2, 3
+
+_vp, _i64, _i32, _u64, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_double
+
+# name -> argtypes; every function returns int.
+SIGNATURES = {
+  'mdlm_subs_logprobs': [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp],
+  'mdlm_subs_row_lse': [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp],
+  'mdlm_subs_argmax': [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp],
+  'mdlm_ddpm_cache_update': [_vp, _i64, _i32, _vp, _vp, _dbl, _vp, _u64, _u64,
+                             _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+  'mdlm_subs_ddpm_update': [_vp, _i64, _i32, _vp, _vp, _vp, _dbl, _vp, _u64,
+                            _u64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+  'mdlm_philox_uniform': [_vp, _i64, _i32, _u64, _u64, _vp],
+  'mdlm_q_xt': [_vp, _vp, _vp, _u64, _u64, _vp, _i32, _i32, _i32, _vp],
+  'mdlm_subs_nll': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
+                    _i32, _vp],
+  'mdlm_nll_sums': [_vp, _vp, _vp, _i64, _vp],
+  'mdlm_embed_rows': [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _vp],
+  'mdlm_timestep_embedding': [_vp, _vp, _i32, _i32, _vp],
+  'mdlm_linear_f32': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+  'mdlm_ln_modulate': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp],
+  'mdlm_gemm_bf16': [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32,
+                     _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp],
+  'mdlm_attn_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
+  'mdlm_compact_active': [_vp, _vp, _vp, _vp, _i32, _i32, _vp],
+}
+
+_lib = None
+
+
+def load():
+  """Load the HIP library (once).  Raises RuntimeError if it is not built."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+      f'{LIB_PATH} is missing: the MI355X HIP extension is not built and '
+      'mdlm_amd has no CPU fallback. Run `python __graft_entry__.py build`.')
+  lib = C.CDLL(LIB_PATH)
+  lib.mdlm_version.restype = C.c_int
+  lib.mdlm_version.argtypes = []
+  lib.mdlm_last_error_string.restype = C.c_char_p
+  lib.mdlm_last_error_string.argtypes = []
+  _lib = lib
+  return lib
+
+
+def _fn(lib, name):
+  fn = getattr(lib, name)  # AttributeError -> the library lacks the symbol
+  if fn.argtypes is None:
+    fn.restype = C.c_int
+    fn.argtypes = SIGNATURES[name]
+  return fn
+
+
+def check_symbols():
+  """Every entry point declared in include/mdlm_hip.h must be exported."""
+  lib = load()
+  missing = [n for n in SIGNATURES if not hasattr(lib, n)]
+  if missing:
+    raise RuntimeError(f'libmdlm_hip.so lacks symbols: {missing}')
+  return sorted(SIGNATURES) + ['mdlm_version', 'mdlm_last_error_string']
+
+
+def call(name, *args):
+  lib = load()
+  rc = _fn(lib, name)(*args)
+  if rc != 0:
+    msg = lib.mdlm_last_error_string().decode('utf-8', 'replace')
+    raise RuntimeError(f'{name} failed (rc={rc}): {msg}')

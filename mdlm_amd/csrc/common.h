@@ -1,0 +1,89 @@
+// Shared helpers for libmdlm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mdlm_hip.h"
+
+#define MDLM_VERSION 100
+
+namespace mdlm {
+
+void set_error(const char* fmt, ...);
+
+#define MDLM_CHECK_ARG(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      mdlm::set_error(__VA_ARGS__);          \
+      return -1;                             \
+    }                                        \
+  } while (0)
+
+#define MDLM_LAUNCH_CHECK()                                        \
+  do {                                                             \
+    hipError_t e__ = hipGetLastError();                            \
+    if (e__ != hipSuccess) {                                       \
+      mdlm::set_error("launch failed: %s", hipGetErrorString(e__)); \
+      return (int)e__;                                             \
+    }                                                              \
+  } while (0)
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((unsigned)v) << 16);
+}
+// round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct elem;
+template <> struct elem<float> {
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct elem<bf16_t> {
+  static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// ---- Philox4x32-10 (counter-based; Salmon et al. 2011) --------------------
+struct Philox {
+  static __device__ __forceinline__ uint4 gen(uint64_t seed, uint64_t ctr) {
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0x6d646c6du, c3 = 0;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+      unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+      c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+  }
+  // 24-bit uniform in [0,1), like torch's CPU float uniform
+  static __device__ __forceinline__ float u01(unsigned x) {
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+  }
+};
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+}  // namespace mdlm

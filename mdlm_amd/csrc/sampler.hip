@@ -1,0 +1,621 @@
+// Sampler-side kernels of the MDLM hot path (HBM-bound, one workgroup per
+// vocab row): SUBS parameterisation, ddpm_cache update with the Gumbel-argmax
+// race, noise-removal argmax, q_xt and the NELBO gather.
+// Reference: diffusion.py:24-28, 261-277, 575-610, 690-697, 884-894.
+#include "common.h"
+
+namespace mdlm {
+
+constexpr int NT = 256;            // threads per row-workgroup (4 waves)
+constexpr float NEG_INF = -1000000.0f;  // diffusion.py:150
+
+// ------------------------------------------------------------------ helpers
+template <typename T> struct vec_traits;
+template <> struct vec_traits<float> { static constexpr int EPV = 4; };
+template <> struct vec_traits<bf16_t> { static constexpr int EPV = 8; };
+
+template <typename T>
+__device__ __forceinline__ void unpack(const uint4& v, float (&f)[vec_traits<T>::EPV]);
+template <>
+__device__ __forceinline__ void unpack<float>(const uint4& v, float (&f)[4]) {
+  f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+  f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+}
+template <>
+__device__ __forceinline__ void unpack<bf16_t>(const uint4& v, float (&f)[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+// elements of `row` before the first 16-byte boundary
+template <typename T>
+__device__ __forceinline__ int row_head(const T* row, int V) {
+  int h = (int)(((16 - ((uintptr_t)row & 15)) & 15) / sizeof(T));
+  return h < V ? h : V;
+}
+
+// Visit every element of a row once: 16-byte vector loads for the aligned
+// body, scalar loads for the (<16 B) head and tail.  fv(idx0, float[EPV]) and
+// fs(idx, float).  Per thread the visited indices are ascending.
+template <typename T, typename FV, typename FS>
+__device__ __forceinline__ void row_visit(const T* row, int V, FV&& fv, FS&& fs) {
+  constexpr int EPV = vec_traits<T>::EPV;
+  const int head = row_head(row, V);
+  for (int i = threadIdx.x; i < head; i += NT) fs(i, elem<T>::load(row + i));
+  const int nvec = (V - head) / EPV;
+  const uint4* vp = reinterpret_cast<const uint4*>(row + head);
+  for (int i = threadIdx.x; i < nvec; i += NT) {
+    float f[EPV];
+    unpack<T>(vp[i], f);
+    fv(head + i * EPV, f);
+  }
+  for (int i = head + nvec * EPV + threadIdx.x; i < V; i += NT)
+    fs(i, elem<T>::load(row + i));
+}
+
+struct LseState {
+  float m = -INFINITY, s = 0.f;
+  __device__ __forceinline__ void add1(float x) {
+    if (x > m) { s = s * __expf(m - x); m = x; }
+    s += __expf(x - m);
+  }
+  template <int N> __device__ __forceinline__ void addv(const float (&x)[N]) {
+    float vm = x[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) vm = fmaxf(vm, x[k]);
+    if (vm > m) { s = s * __expf(m - vm); m = vm; }
+#pragma unroll
+    for (int k = 0; k < N; ++k) s += __expf(x[k] - m);
+  }
+};
+
+// block-wide log-sum-exp from per-thread online states; result in all threads
+__device__ __forceinline__ float block_lse(LseState st, float* sm /*[2*4+1]*/) {
+  float M = wave_max(st.m);
+  float s = (st.m == -INFINITY) ? 0.f : st.s * __expf(st.m - M);
+  float S = wave_sum(s);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[w] = M; sm[4 + w] = S; }
+  __syncthreads();
+  float Mb = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  float Sb = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) Sb += sm[4 + i] * __expf(sm[i] - Mb);
+  __syncthreads();
+  return Mb + logf(Sb);
+}
+
+// SUBS row log-sum-exp with the mask column shifted by -1e6 (diffusion.py:263-268)
+template <typename T>
+__device__ __forceinline__ float subs_row_lse(const T* row, int V, int mask, float* sm) {
+  LseState st;
+  constexpr int EPV = vec_traits<T>::EPV;
+  row_visit<T>(row, V,
+    [&](int i0, float (&f)[EPV]) {
+      if (mask >= i0 && mask < i0 + EPV) {
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) if (i0 + k == mask) f[k] += NEG_INF;
+      }
+      st.addv(f);
+    },
+    [&](int i, float x) { st.add1(i == mask ? x + NEG_INF : x); });
+  return block_lse(st, sm);
+}
+
+struct ArgMax {
+  float v = -INFINITY; int i = 0x7fffffff;
+  // torch.argmax semantics: NaN counts as the maximum and the first index
+  // wins ties; per thread the visit order is ascending, so strict > suffices.
+  __device__ __forceinline__ void put(float x, int idx) {
+    if (i == 0x7fffffff) { v = x; i = idx; return; }
+    if (v != v) return;
+    if (x > v || x != x) { v = x; i = idx; }
+  }
+};
+__device__ __forceinline__ bool am_better(float av, int ai, float bv, int bi) {
+  // torch.argmax: NaN counts as the maximum; first index wins ties
+  const bool an = av != av, bn = bv != bv;
+  if (an != bn) return an;
+  if (!an && av != bv) return av > bv;
+  return ai < bi;
+}
+__device__ __forceinline__ int block_argmax(ArgMax a, float* smv, int* smi) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(a.v, o); int oi = __shfl_xor(a.i, o);
+    if (am_better(ov, oi, a.v, a.i)) { a.v = ov; a.i = oi; }
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { smv[w] = a.v; smi[w] = a.i; }
+  __syncthreads();
+  float bv = smv[0]; int bi = smi[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (am_better(smv[k], smi[k], bv, bi)) { bv = smv[k]; bi = smi[k]; }
+  __syncthreads();
+  return bi;
+}
+
+// ------------------------------------------------------ (a) SUBS log-probs
+template <typename TI, typename TO>
+__global__ __launch_bounds__(NT) void subs_logprobs_kernel(
+    const TI* __restrict__ logits, int64_t ld_in, const int64_t* __restrict__ xt,
+    TO* __restrict__ out, int64_t ld_out, int V, int mask) {
+  __shared__ float sm[9];
+  const int64_t r = blockIdx.x;
+  const TI* row = logits + r * ld_in;
+  TO* orow = out + r * ld_out;
+  const int64_t tok = xt[r];
+  if (tok != mask) {  // diffusion.py:274-276
+    for (int i = threadIdx.x; i < V; i += NT)
+      elem<TO>::store(orow + i, i == tok ? 0.f : NEG_INF);
+    return;
+  }
+  const float lse = subs_row_lse<TI>(row, V, mask, sm);
+  for (int i = threadIdx.x; i < V; i += NT) {
+    float x = elem<TI>::load(row + i);
+    if (i == mask) x += NEG_INF;
+    elem<TO>::store(orow + i, x - lse);
+  }
+}
+
+// vectorised variant: both rows 16-byte aligned, same element type
+template <typename T>
+__global__ __launch_bounds__(NT) void subs_logprobs_vec_kernel(
+    const T* __restrict__ logits, int64_t ld_in, const int64_t* __restrict__ xt,
+    T* __restrict__ out, int64_t ld_out, int V, int mask) {
+  __shared__ float sm[9];
+  constexpr int EPV = vec_traits<T>::EPV;
+  const int64_t r = blockIdx.x;
+  const T* row = logits + r * ld_in;
+  T* orow = out + r * ld_out;
+  const int64_t tok = xt[r];
+  const int nvec = V / EPV;
+  uint4* ov = reinterpret_cast<uint4*>(orow);
+  auto pack = [](const float (&f)[EPV]) {
+    uint4 o;
+    if constexpr (EPV == 4) {
+      o = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]),
+                     __float_as_uint(f[2]), __float_as_uint(f[3]));
+    } else {
+      o = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
+                     pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+    }
+    return o;
+  };
+  if (tok != mask) {
+    for (int i = threadIdx.x; i < nvec; i += NT) {
+      float f[EPV];
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) f[k] = (i * EPV + k == tok) ? 0.f : NEG_INF;
+      ov[i] = pack(f);
+    }
+    for (int i = nvec * EPV + threadIdx.x; i < V; i += NT)
+      elem<T>::store(orow + i, i == tok ? 0.f : NEG_INF);
+    return;
+  }
+  const float lse = subs_row_lse<T>(row, V, mask, sm);
+  const uint4* iv = reinterpret_cast<const uint4*>(row);
+  for (int i = threadIdx.x; i < nvec; i += NT) {
+    float f[EPV];
+    unpack<T>(iv[i], f);
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) {
+      if (i * EPV + k == mask) f[k] += NEG_INF;
+      f[k] -= lse;
+    }
+    ov[i] = pack(f);
+  }
+  for (int i = nvec * EPV + threadIdx.x; i < V; i += NT) {
+    float x = elem<T>::load(row + i);
+    if (i == mask) x += NEG_INF;
+    elem<T>::store(orow + i, x - lse);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void subs_row_lse_kernel(
+    const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ xt,
+    float* __restrict__ lse, int V, int mask) {
+  __shared__ float sm[9];
+  const int64_t r = blockIdx.x;
+  if (xt[r] != mask) { if (threadIdx.x == 0) lse[r] = 0.f; return; }
+  const float v = subs_row_lse<T>(logits + r * ld, V, mask, sm);
+  if (threadIdx.x == 0) lse[r] = v;
+}
+
+// --------------------------------------------------- (a') noise removal argmax
+template <typename T>
+__global__ __launch_bounds__(NT) void subs_argmax_kernel(
+    const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ xt,
+    int64_t* __restrict__ out, int V, int mask) {
+  __shared__ float smv[4]; __shared__ int smi[4];
+  constexpr int EPV = vec_traits<T>::EPV;
+  const int64_t r = blockIdx.x;
+  const int64_t tok = xt[r];
+  if (tok != mask) { if (threadIdx.x == 0) out[r] = tok; return; }
+  // argmax(logit - lse) == argmax(shifted logit): subtracting the row
+  // constant is monotone; ties broken by first index like torch.argmax.
+  ArgMax am;
+  row_visit<T>(logits + r * ld, V,
+    [&](int i0, float (&f)[EPV]) {
+#pragma unroll
+      for (int k = 0; k < EPV; ++k)
+        am.put(i0 + k == mask ? f[k] + NEG_INF : f[k], i0 + k);
+    },
+    [&](int i, float x) { am.put(i == mask ? x + NEG_INF : x, i); });
+  const int best = block_argmax(am, smv, smi);
+  if (threadIdx.x == 0) out[r] = best;
+}
+
+// ----------------------------------------- (b) ddpm_cache update / Gumbel race
+template <bool FAST>
+__device__ __forceinline__ float race(float q, float u) {
+  // diffusion.py:25-28: q / (1e-10 - log(u + 1e-10))
+  if constexpr (FAST) {
+    const float g = 1e-10f - __logf(u + 1e-10f);
+    return __fdividef(q, g);
+  } else {
+    // log in fp64, rounded once: correctly rounded fp32 log
+    const float g = 1e-10f - (float)log((double)(u + 1e-10f));
+    return q / g;
+  }
+}
+
+// SRC 0: row holds probabilities p_x0.  SRC 1: row holds raw logits + lse.
+template <int SRC, bool FAST>
+__device__ __forceinline__ float q_of(float x, int v, int mask, float lse,
+                                      float factor, float ms) {
+  if (v == mask) return ms;  // diffusion.py:606
+  float p;
+  if constexpr (SRC == 0) p = x;
+  else p = FAST ? __expf(x - lse) : expf(x - lse);
+  return p * factor;  // diffusion.py:605
+}
+
+template <typename T, int SRC, bool FAST, bool PHILOX>
+__global__ __launch_bounds__(NT) void ddpm_update_kernel(
+    const T* __restrict__ src, int64_t ld, const float* __restrict__ lse_arr,
+    const int64_t* __restrict__ x, const float* __restrict__ t, float dt,
+    const float* __restrict__ u, uint64_t seed, uint64_t offset,
+    int64_t* __restrict__ x_next, int32_t* __restrict__ changed, int L, int V,
+    int mask) {
+  __shared__ float smv[4]; __shared__ int smi[4];
+  constexpr int EPV = vec_traits<T>::EPV;
+  const int64_t r = blockIdx.x;
+  const int64_t tok = x[r];
+  if (tok != mask) {  // carry-over, diffusion.py:609-610
+    if (threadIdx.x == 0) x_next[r] = tok;
+    return;
+  }
+  const int b = (int)(r / L);
+  const float mt = t[b];
+  const float ms = mt - dt;          // diffusion.py:599 (fp32)
+  const float factor = mt - ms;      // diffusion.py:605 (not fp32(dt))
+  const float lse = SRC == 1 ? lse_arr[r] : 0.f;
+  const T* row = src + r * ld;
+  ArgMax am;
+  const uint64_t G = (uint64_t)((V + 3) >> 2);
+  const uint64_t ctr0 = offset + (uint64_t)r * G;
+  if constexpr (PHILOX) {
+    if (row_head(row, V) == 0) {
+      // aligned fast path: 16-byte loads, EPV/4 Philox groups per vector
+      const int nvec = V / EPV;
+      const uint4* vp = reinterpret_cast<const uint4*>(row);
+      for (int i = threadIdx.x; i < nvec; i += NT) {
+        float f[EPV];
+        unpack<T>(vp[i], f);
+#pragma unroll
+        for (int gq = 0; gq < EPV / 4; ++gq) {
+          const int v0 = i * EPV + gq * 4;
+          const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)(v0 >> 2));
+          const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float q = q_of<SRC, FAST>(f[gq * 4 + k], v0 + k, mask, lse, factor, ms);
+            am.put(race<FAST>(q, Philox::u01(rr[k])), v0 + k);
+          }
+        }
+      }
+      for (int v = nvec * EPV + threadIdx.x; v < V; v += NT) {
+        const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)(v >> 2));
+        const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
+        const float q = q_of<SRC, FAST>(elem<T>::load(row + v), v, mask, lse, factor, ms);
+        am.put(race<FAST>(q, Philox::u01(rr[v & 3])), v);
+      }
+    } else {
+      // unaligned rows: one Philox group (4 consecutive columns) per thread
+      for (int g = threadIdx.x; g < (int)G; g += NT) {
+        const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)g);
+        const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int v = g * 4 + k;
+          if (v < V) {
+            const float q = q_of<SRC, FAST>(elem<T>::load(row + v), v, mask, lse, factor, ms);
+            am.put(race<FAST>(q, Philox::u01(rr[k])), v);
+          }
+        }
+      }
+    }
+  } else {
+    const float* urow = u + r * (int64_t)V;
+    for (int v = threadIdx.x; v < V; v += NT) {
+      const float q = q_of<SRC, FAST>(elem<T>::load(row + v), v, mask, lse, factor, ms);
+      am.put(race<FAST>(q, urow[v]), v);
+    }
+  }
+  const int best = block_argmax(am, smv, smi);
+  if (threadIdx.x == 0) {
+    x_next[r] = best;
+    if (best != mask && changed) changed[b] = 1;  // benign race: all write 1
+  }
+}
+
+__global__ void philox_uniform_kernel(float* out, int64_t rows, int V,
+                                      uint64_t seed, uint64_t offset) {
+  const uint64_t G = (uint64_t)((V + 3) >> 2);
+  const int64_t r = blockIdx.x;
+  for (int g = threadIdx.x; g < (int)G; g += blockDim.x) {
+    const uint4 rn = Philox::gen(seed, offset + (uint64_t)r * G + (uint64_t)g);
+    const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
+    for (int k = 0; k < 4; ++k)
+      if (g * 4 + k < V) out[r * (int64_t)V + g * 4 + k] = Philox::u01(rr[k]);
+  }
+}
+
+// ------------------------------------------------------------- (c1) q_xt
+__global__ void q_xt_kernel(const int64_t* __restrict__ x0,
+                            const float* __restrict__ move_chance,
+                            const float* __restrict__ u, uint64_t seed,
+                            uint64_t offset, int64_t* __restrict__ xt, int64_t n,
+                            int L, int mask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float ui;
+  if (u) ui = u[i];
+  else {
+    const uint4 rn = Philox::gen(seed, offset + (uint64_t)(i >> 2));
+    const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
+    ui = Philox::u01(rr[i & 3]);
+  }
+  xt[i] = (ui < move_chance[i / L]) ? (int64_t)mask : x0[i];  // diffusion.py:583-585
+}
+
+// ----------------------------------------------------------- (c2) SUBS NLL
+template <typename T>
+__global__ __launch_bounds__(NT) void subs_nll_kernel(
+    const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ xt,
+    const int64_t* __restrict__ x0, const float* __restrict__ weight,
+    const float* __restrict__ attn_mask, float* __restrict__ nll, int L, int V,
+    int mask) {
+  __shared__ float sm[9];
+  const int64_t r = blockIdx.x;
+  const int64_t tok = xt[r], tgt = x0[r];
+  const float w = weight[r / L];
+  const float am = attn_mask ? attn_mask[r] : 1.f;
+  float logp;
+  if (tok != mask) {
+    logp = (tgt == tok) ? 0.f : NEG_INF;  // diffusion.py:274-276
+  } else {
+    const T* row = logits + r * ld;
+    const float lse = subs_row_lse<T>(row, V, mask, sm);
+    float x = elem<T>::load(row + tgt);
+    if (tgt == mask) x += NEG_INF;
+    logp = x - lse;
+  }
+  // diffusion.py:893-894 then 908
+  if (threadIdx.x == 0) nll[r] = (-logp * w) * am;
+}
+
+__global__ __launch_bounds__(1024) void nll_sums_kernel(
+    const float* __restrict__ nll, const float* __restrict__ attn_mask,
+    double* __restrict__ sums, int64_t n) {
+  __shared__ double s0[1024], s1[1024];
+  double a = 0.0, c = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    a += (double)nll[i];
+    c += attn_mask ? (double)attn_mask[i] : 1.0;
+  }
+  s0[threadIdx.x] = a; s1[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { s0[threadIdx.x] += s0[threadIdx.x + o]; s1[threadIdx.x] += s1[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { sums[0] += s0[0]; sums[1] += s1[0]; }
+}
+
+__global__ void compact_active_kernel(const int32_t* __restrict__ changed,
+                                      int32_t* __restrict__ active,
+                                      int32_t* __restrict__ n_active,
+                                      int32_t* __restrict__ n_rows, int B, int L) {
+  // single wave; ordered compaction via ballot, 64 samples per pass
+  int base = 0;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int b = b0 + threadIdx.x;
+    const bool on = b < B && changed[b] != 0;
+    const unsigned long long m = __ballot(on);
+    if (on) active[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = b;
+    base += __popcll(m);
+  }
+  if (threadIdx.x == 0) { *n_active = base; *n_rows = base * L; }
+}
+
+static bool is16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace mdlm
+
+using namespace mdlm;
+
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int mdlm_subs_logprobs(const void* logits, int64_t ld_in, int dtype_in,
+                                  const int64_t* xt, void* out, int64_t ld_out,
+                                  int dtype_out, int64_t rows, int V,
+                                  int mask_index, void* stream) {
+  MDLM_CHECK_ARG(logits && xt && out, "subs_logprobs: null pointer");
+  MDLM_CHECK_ARG(rows >= 0 && rows < (1ll << 31) && V > 0 && ld_in >= V && ld_out >= V,
+                 "subs_logprobs: bad shape rows=%lld V=%d ld_in=%lld ld_out=%lld",
+                 (long long)rows, V, (long long)ld_in, (long long)ld_out);
+  MDLM_CHECK_ARG(mask_index >= 0 && mask_index < V, "subs_logprobs: mask_index %d outside [0,%d)", mask_index, V);
+  MDLM_CHECK_ARG((dtype_in == MDLM_F32 || dtype_in == MDLM_BF16) &&
+                 (dtype_out == MDLM_F32 || dtype_out == MDLM_BF16), "subs_logprobs: bad dtype");
+  if (rows == 0) return 0;
+  dim3 g((unsigned)rows), b(NT);
+  const size_t es = dtype_in == MDLM_F32 ? 4 : 2;
+  const bool vec = dtype_in == dtype_out && is16(logits) && is16(out) &&
+                   (ld_in * es) % 16 == 0 && (ld_out * es) % 16 == 0;
+  if (dtype_in == MDLM_F32 && dtype_out == MDLM_F32) {
+    if (vec) subs_logprobs_vec_kernel<float><<<g, b, 0, ST(stream)>>>((const float*)logits, ld_in, xt, (float*)out, ld_out, V, mask_index);
+    else subs_logprobs_kernel<float, float><<<g, b, 0, ST(stream)>>>((const float*)logits, ld_in, xt, (float*)out, ld_out, V, mask_index);
+  } else if (dtype_in == MDLM_BF16 && dtype_out == MDLM_BF16) {
+    if (vec) subs_logprobs_vec_kernel<bf16_t><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index);
+    else subs_logprobs_kernel<bf16_t, bf16_t><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index);
+  } else if (dtype_in == MDLM_BF16) {
+    subs_logprobs_kernel<bf16_t, float><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (float*)out, ld_out, V, mask_index);
+  } else {
+    subs_logprobs_kernel<float, bf16_t><<<g, b, 0, ST(stream)>>>((const float*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index);
+  }
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_subs_row_lse(const void* logits, int64_t ld, int dtype,
+                                 const int64_t* xt, float* lse, int64_t rows,
+                                 int V, int mask_index, void* stream) {
+  MDLM_CHECK_ARG(logits && xt && lse, "subs_row_lse: null pointer");
+  MDLM_CHECK_ARG(rows >= 0 && rows < (1ll << 31) && V > 0 && ld >= V, "subs_row_lse: bad shape");
+  MDLM_CHECK_ARG(mask_index >= 0 && mask_index < V, "subs_row_lse: mask_index out of range");
+  MDLM_CHECK_ARG(dtype == MDLM_F32 || dtype == MDLM_BF16, "subs_row_lse: bad dtype");
+  if (rows == 0) return 0;
+  if (dtype == MDLM_F32) subs_row_lse_kernel<float><<<(unsigned)rows, NT, 0, ST(stream)>>>((const float*)logits, ld, xt, lse, V, mask_index);
+  else subs_row_lse_kernel<bf16_t><<<(unsigned)rows, NT, 0, ST(stream)>>>((const bf16_t*)logits, ld, xt, lse, V, mask_index);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_subs_argmax(const void* logits, int64_t ld, int dtype,
+                                const int64_t* xt, int64_t* out, int64_t rows,
+                                int V, int mask_index, void* stream) {
+  MDLM_CHECK_ARG(logits && xt && out, "subs_argmax: null pointer");
+  MDLM_CHECK_ARG(rows >= 0 && rows < (1ll << 31) && V > 0 && ld >= V, "subs_argmax: bad shape");
+  MDLM_CHECK_ARG(mask_index >= 0 && mask_index < V, "subs_argmax: mask_index out of range");
+  MDLM_CHECK_ARG(dtype == MDLM_F32 || dtype == MDLM_BF16, "subs_argmax: bad dtype");
+  if (rows == 0) return 0;
+  if (dtype == MDLM_F32) subs_argmax_kernel<float><<<(unsigned)rows, NT, 0, ST(stream)>>>((const float*)logits, ld, xt, out, V, mask_index);
+  else subs_argmax_kernel<bf16_t><<<(unsigned)rows, NT, 0, ST(stream)>>>((const bf16_t*)logits, ld, xt, out, V, mask_index);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int SRC>
+static int launch_update(const void* src, int64_t ld, int dtype, const float* lse,
+                         const int64_t* x, const float* t, double dt,
+                         const float* u, uint64_t seed, uint64_t offset,
+                         int64_t* x_next, int32_t* changed, int B, int L, int V,
+                         int mask_index, int fast_math, void* stream) {
+  const char* nm = SRC ? "subs_ddpm_update" : "ddpm_cache_update";
+  MDLM_CHECK_ARG(src && x && t && x_next, "%s: null pointer", nm);
+  MDLM_CHECK_ARG(SRC == 0 || lse, "%s: lse is required", nm);
+  MDLM_CHECK_ARG(B >= 0 && L > 0 && V > 0 && ld >= V && (int64_t)B * L < (1ll << 31), "%s: bad shape B=%d L=%d V=%d ld=%lld", nm, B, L, V, (long long)ld);
+  MDLM_CHECK_ARG(mask_index >= 0 && mask_index < V, "%s: mask_index out of range", nm);
+  MDLM_CHECK_ARG(dtype == MDLM_F32 || dtype == MDLM_BF16, "%s: bad dtype", nm);
+  if (B == 0) return 0;
+  hipStream_t s = ST(stream);
+  if (changed) {
+    hipError_t e = hipMemsetAsync(changed, 0, sizeof(int32_t) * (size_t)B, s);
+    if (e != hipSuccess) { set_error("%s: memset failed: %s", nm, hipGetErrorString(e)); return (int)e; }
+  }
+  const unsigned rows = (unsigned)((int64_t)B * L);
+  const float dtf = (float)dt;  // python float -> fp32 scalar, as torch does
+#define MDLM_UPD(T, FAST, PH) \
+  ddpm_update_kernel<T, SRC, FAST, PH><<<rows, NT, 0, s>>>((const T*)src, ld, lse, x, t, dtf, u, seed, offset, x_next, changed, L, V, mask_index)
+  const bool ph = (u == nullptr), fast = fast_math != 0;
+  if (dtype == MDLM_F32) {
+    if (ph) { if (fast) MDLM_UPD(float, true, true); else MDLM_UPD(float, false, true); }
+    else    { if (fast) MDLM_UPD(float, true, false); else MDLM_UPD(float, false, false); }
+  } else {
+    if (ph) { if (fast) MDLM_UPD(bf16_t, true, true); else MDLM_UPD(bf16_t, false, true); }
+    else    { if (fast) MDLM_UPD(bf16_t, true, false); else MDLM_UPD(bf16_t, false, false); }
+  }
+#undef MDLM_UPD
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_ddpm_cache_update(const void* p_x0, int64_t ld, int dtype,
+                                      const int64_t* x, const float* t, double dt,
+                                      const float* u, uint64_t seed, uint64_t offset,
+                                      int64_t* x_next, int32_t* changed, int B,
+                                      int L, int V, int mask_index, int fast_math,
+                                      void* stream) {
+  return launch_update<0>(p_x0, ld, dtype, nullptr, x, t, dt, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
+}
+
+extern "C" int mdlm_subs_ddpm_update(const void* logits, int64_t ld, int dtype,
+                                     const float* lse, const int64_t* x,
+                                     const float* t, double dt, const float* u,
+                                     uint64_t seed, uint64_t offset,
+                                     int64_t* x_next, int32_t* changed, int B,
+                                     int L, int V, int mask_index, int fast_math,
+                                     void* stream) {
+  return launch_update<1>(logits, ld, dtype, lse, x, t, dt, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
+}
+
+extern "C" int mdlm_philox_uniform(float* out, int64_t rows, int V, uint64_t seed,
+                                   uint64_t offset, void* stream) {
+  MDLM_CHECK_ARG(out && rows >= 0 && rows < (1ll << 31) && V > 0, "philox_uniform: bad args");
+  if (rows == 0) return 0;
+  philox_uniform_kernel<<<(unsigned)rows, 256, 0, ST(stream)>>>(out, rows, V, seed, offset);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_q_xt(const int64_t* x0, const float* move_chance,
+                         const float* u, uint64_t seed, uint64_t offset,
+                         int64_t* xt, int B, int L, int mask_index, void* stream) {
+  MDLM_CHECK_ARG(x0 && move_chance && xt, "q_xt: null pointer");
+  MDLM_CHECK_ARG(B >= 0 && L > 0, "q_xt: bad shape");
+  const int64_t n = (int64_t)B * L;
+  if (n == 0) return 0;
+  q_xt_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ST(stream)>>>(x0, move_chance, u, seed, offset, xt, n, L, mask_index);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_subs_nll(const void* logits, int64_t ld, int dtype,
+                             const int64_t* xt, const int64_t* x0,
+                             const float* weight, const float* attn_mask,
+                             float* nll, int B, int L, int V, int mask_index,
+                             void* stream) {
+  MDLM_CHECK_ARG(logits && xt && x0 && weight && nll, "subs_nll: null pointer");
+  MDLM_CHECK_ARG(B >= 0 && L > 0 && V > 0 && ld >= V && (int64_t)B * L < (1ll << 31), "subs_nll: bad shape");
+  MDLM_CHECK_ARG(mask_index >= 0 && mask_index < V, "subs_nll: mask_index out of range");
+  MDLM_CHECK_ARG(dtype == MDLM_F32 || dtype == MDLM_BF16, "subs_nll: bad dtype");
+  if (B == 0) return 0;
+  const unsigned rows = (unsigned)((int64_t)B * L);
+  if (dtype == MDLM_F32) subs_nll_kernel<float><<<rows, NT, 0, ST(stream)>>>((const float*)logits, ld, xt, x0, weight, attn_mask, nll, L, V, mask_index);
+  else subs_nll_kernel<bf16_t><<<rows, NT, 0, ST(stream)>>>((const bf16_t*)logits, ld, xt, x0, weight, attn_mask, nll, L, V, mask_index);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_nll_sums(const float* nll, const float* attn_mask,
+                             double* sums, int64_t n, void* stream) {
+  MDLM_CHECK_ARG(nll && sums && n >= 0, "nll_sums: bad args");
+  nll_sums_kernel<<<1, 1024, 0, ST(stream)>>>(nll, attn_mask, sums, n);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_compact_active(const int32_t* changed, int32_t* active,
+                                   int32_t* n_active, int32_t* n_rows, int B,
+                                   int L, void* stream) {
+  MDLM_CHECK_ARG(changed && active && n_active && n_rows && B >= 0 && L > 0, "compact_active: bad args");
+  compact_active_kernel<<<1, 64, 0, ST(stream)>>>(changed, active, n_active, n_rows, B, L);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,267 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/mdlm_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; all arithmetic
+runs in the hand-written HIP kernels.  Every wrapper requires CUDA (ROCm)
+tensors and raises otherwise -- there is no CPU path.
+"""
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, call
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _stream():
+  return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name, dtype=None):
+  if not isinstance(t, torch.Tensor) or not t.is_cuda:
+    raise RuntimeError(
+      f'{name}: expected a CUDA/ROCm tensor; mdlm_amd has no CPU fallback')
+  if dtype is not None and t.dtype != dtype:
+    raise RuntimeError(f'{name}: expected dtype {dtype}, got {t.dtype}')
+  return t
+
+
+def _rows2d(t, name):
+  """View (..., V) as rows with a leading dimension; innermost contiguous."""
+  _dev(t, name)
+  if t.dtype not in _DT:
+    raise RuntimeError(f'{name}: dtype {t.dtype} not supported (fp32/bf16)')
+  if t.stride(-1) != 1:
+    raise RuntimeError(f'{name}: innermost dimension must be contiguous')
+  V = t.shape[-1]
+  if t.dim() == 2:
+    return t, t.shape[0], V, t.stride(0)
+  if t.dim() == 3:
+    B, L, _ = t.shape
+    ld = t.stride(1)
+    if B > 1 and t.stride(0) != L * ld:
+      raise RuntimeError(f'{name}: rows must be uniformly strided')
+    return t, B * L, V, ld
+  raise RuntimeError(f'{name}: expected 2-D or 3-D tensor')
+
+
+def _p(t):
+  return 0 if t is None else t.data_ptr()
+
+
+def padded_vocab(V, multiple=128):
+  return (V + multiple - 1) // multiple * multiple
+
+
+def alloc_logits(B, L, V, dtype=torch.bfloat16, device='cuda'):
+  """(B, L, V) view of a buffer whose rows are padded to a multiple of 128
+  elements, so every row starts 16-byte aligned (vector loads/stores)."""
+  buf = torch.empty(B, L, padded_vocab(V), dtype=dtype, device=device)
+  return buf[:, :, :V]
+
+
+# ------------------------------------------------------------------ sampler
+def subs_logprobs(logits, xt, mask_index, out=None, out_dtype=None):
+  lg, rows, V, ld = _rows2d(logits, 'logits')
+  xt = _dev(xt, 'xt', torch.int64).contiguous()
+  assert xt.numel() == rows
+  if out is None:
+    od = out_dtype or logits.dtype
+    if logits.dim() == 3:
+      out = alloc_logits(logits.shape[0], logits.shape[1], V, od, logits.device)
+    else:
+      out = torch.empty(rows, padded_vocab(V), dtype=od,
+                        device=logits.device)[:, :V]
+  o, orows, oV, old = _rows2d(out, 'out')
+  assert orows == rows and oV == V
+  call('mdlm_subs_logprobs', lg.data_ptr(), ld, _DT[lg.dtype], xt.data_ptr(),
+       o.data_ptr(), old, _DT[o.dtype], rows, V, int(mask_index), _stream())
+  return out
+
+
+def subs_row_lse(logits, xt, mask_index, out=None):
+  lg, rows, V, ld = _rows2d(logits, 'logits')
+  xt = _dev(xt, 'xt', torch.int64).contiguous()
+  if out is None:
+    out = torch.empty(rows, dtype=torch.float32, device=logits.device)
+  call('mdlm_subs_row_lse', lg.data_ptr(), ld, _DT[lg.dtype], xt.data_ptr(),
+       out.data_ptr(), rows, V, int(mask_index), _stream())
+  return out
+
+
+def subs_argmax(logits, xt, mask_index, out=None):
+  lg, rows, V, ld = _rows2d(logits, 'logits')
+  xt = _dev(xt, 'xt', torch.int64).contiguous()
+  if out is None:
+    out = torch.empty_like(xt)
+  call('mdlm_subs_argmax', lg.data_ptr(), ld, _DT[lg.dtype], xt.data_ptr(),
+       out.data_ptr(), rows, V, int(mask_index), _stream())
+  return out
+
+
+def _t_vec(t, B):
+  t = _dev(t, 't')
+  if t.dim() > 1:
+    t = t.squeeze(-1)  # diffusion.py:595-596
+  assert t.dim() == 1 and t.shape[0] == B
+  return t.to(torch.float32).contiguous()
+
+
+def ddpm_cache_update(p_x0, x, t, dt, mask_index, u=None, seed=0, offset=0,
+                      changed=None, fast_math=False, x_next=None):
+  """(b) from probabilities.  Returns x_next (and fills `changed` (B,) int32)."""
+  p, rows, V, ld = _rows2d(p_x0, 'p_x0')
+  x = _dev(x, 'x', torch.int64).contiguous()
+  B, L = x.shape
+  assert rows == B * L
+  tt = _t_vec(t, B)
+  if u is not None:
+    u = _dev(u, 'u', torch.float32).contiguous()
+    assert u.numel() == rows * V
+  if x_next is None:
+    x_next = torch.empty_like(x)
+  call('mdlm_ddpm_cache_update', p.data_ptr(), ld, _DT[p.dtype], x.data_ptr(),
+       tt.data_ptr(), float(dt), _p(u), int(seed), int(offset),
+       x_next.data_ptr(), _p(changed), B, L, V, int(mask_index),
+       int(bool(fast_math)), _stream())
+  return x_next
+
+
+def subs_ddpm_update(logits, lse, x, t, dt, mask_index, u=None, seed=0,
+                     offset=0, changed=None, fast_math=False, x_next=None):
+  """(a)+(b) fused from raw logits + row lse."""
+  lg, rows, V, ld = _rows2d(logits, 'logits')
+  x = _dev(x, 'x', torch.int64).contiguous()
+  B, L = x.shape
+  assert rows == B * L
+  lse = _dev(lse, 'lse', torch.float32).contiguous()
+  assert lse.numel() == rows
+  tt = _t_vec(t, B)
+  if u is not None:
+    u = _dev(u, 'u', torch.float32).contiguous()
+    assert u.numel() == rows * V
+  if x_next is None:
+    x_next = torch.empty_like(x)
+  call('mdlm_subs_ddpm_update', lg.data_ptr(), ld, _DT[lg.dtype],
+       lse.data_ptr(), x.data_ptr(), tt.data_ptr(), float(dt), _p(u),
+       int(seed), int(offset), x_next.data_ptr(), _p(changed), B, L, V,
+       int(mask_index), int(bool(fast_math)), _stream())
+  return x_next
+
+
+def philox_uniform(rows, V, seed, offset=0, device='cuda'):
+  out = torch.empty(rows, V, dtype=torch.float32, device=device)
+  call('mdlm_philox_uniform', out.data_ptr(), rows, V, int(seed), int(offset),
+       _stream())
+  return out
+
+
+def q_xt(x0, move_chance, mask_index, u=None, seed=0, offset=0):
+  x0 = _dev(x0, 'x0', torch.int64).contiguous()
+  B, L = x0.shape
+  mc = _dev(move_chance, 'move_chance').to(torch.float32).reshape(-1).contiguous()
+  assert mc.numel() == B
+  if u is not None:
+    u = _dev(u, 'u', torch.float32).contiguous()
+    assert u.shape == x0.shape
+  xt = torch.empty_like(x0)
+  call('mdlm_q_xt', x0.data_ptr(), mc.data_ptr(), _p(u), int(seed),
+       int(offset), xt.data_ptr(), B, L, int(mask_index), _stream())
+  return xt
+
+
+def subs_nll(logits, xt, x0, weight, mask_index, attn_mask=None):
+  lg, rows, V, ld = _rows2d(logits, 'logits')
+  xt = _dev(xt, 'xt', torch.int64).contiguous()
+  x0 = _dev(x0, 'x0', torch.int64).contiguous()
+  B, L = xt.shape
+  assert rows == B * L
+  w = _dev(weight, 'weight').to(torch.float32).reshape(-1).contiguous()
+  assert w.numel() == B
+  if attn_mask is not None:
+    attn_mask = _dev(attn_mask, 'attn_mask').to(torch.float32).contiguous()
+  nll = torch.empty(B, L, dtype=torch.float32, device=logits.device)
+  call('mdlm_subs_nll', lg.data_ptr(), ld, _DT[lg.dtype], xt.data_ptr(),
+       x0.data_ptr(), w.data_ptr(), _p(attn_mask), nll.data_ptr(), B, L, V,
+       int(mask_index), _stream())
+  return nll
+
+
+def nll_sums(nll, attn_mask=None, sums=None):
+  nll = _dev(nll, 'nll', torch.float32).contiguous()
+  if attn_mask is not None:
+    attn_mask = _dev(attn_mask, 'attn_mask').to(torch.float32).contiguous()
+  if sums is None:
+    sums = torch.zeros(2, dtype=torch.float64, device=nll.device)
+  call('mdlm_nll_sums', nll.data_ptr(), _p(attn_mask), sums.data_ptr(),
+       nll.numel(), _stream())
+  return sums
+
+
+def compact_active(changed, active, n_active, n_rows, L):
+  call('mdlm_compact_active', changed.data_ptr(), active.data_ptr(),
+       n_active.data_ptr(), n_rows.data_ptr(), changed.numel(), int(L),
+       _stream())
+
+
+# ---------------------------------------------------------------- DiT ops
+def embed_rows(table, idx, out, sample_map=None, L=1, n_rows_dev=None):
+  n_rows, D = out.shape
+  call('mdlm_embed_rows', table.data_ptr(), idx.data_ptr(), _p(sample_map),
+       int(L), out.data_ptr(), n_rows, D, table.shape[0], _p(n_rows_dev),
+       _stream())
+  return out
+
+
+def timestep_embedding(t, dim):
+  t = _dev(t, 't', torch.float32).contiguous()
+  out = torch.empty(t.shape[0], dim, dtype=torch.float32, device=t.device)
+  call('mdlm_timestep_embedding', t.data_ptr(), out.data_ptr(), t.shape[0],
+       dim, _stream())
+  return out
+
+
+def linear_f32(x, W, bias, act_in=0, act_out=0):
+  x = _dev(x, 'x', torch.float32).contiguous()
+  B, K = x.shape
+  N = W.shape[0]
+  assert W.shape[1] == K and W.is_contiguous() and W.dtype == torch.float32
+  out = torch.empty(B, N, dtype=torch.float32, device=x.device)
+  call('mdlm_linear_f32', x.data_ptr(), W.data_ptr(), _p(bias), out.data_ptr(),
+       B, N, K, act_in, act_out, _stream())
+  return out
+
+
+def ln_modulate(x, ln_w, shift, scale, out, rows_per_mod, n_rows_dev=None):
+  rows, D = x.shape
+  n_mod = shift.shape[0]
+  assert shift.shape == scale.shape == (n_mod, D)
+  call('mdlm_ln_modulate', x.data_ptr(), ln_w.data_ptr(), shift.data_ptr(),
+       scale.data_ptr(), out.data_ptr(), rows, D, rows_per_mod, n_mod,
+       _p(n_rows_dev), _stream())
+  return out
+
+
+def gemm_bf16(A, W, C, epilogue=_lib.EPI_STORE, bias=None, gate=None,
+              residual=None, rows_per_mod=1, n_mod=1, rot_cos=None,
+              rot_sin=None, n_heads=0, m_rows_dev=None, ldc=None, M=None):
+  """C = epilogue(A @ W^T); see include/mdlm_hip.h (mdlm_gemm_bf16)."""
+  if M is None:
+    M = A.shape[0]
+  K = A.shape[1]
+  N = W.shape[0]
+  assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16
+  assert W.shape[1] == K and W.is_contiguous() and A.stride(1) == 1
+  if ldc is None:
+    ldc = C.stride(0) if C.dim() == 2 else 0
+  dt_c = _DT[C.dtype]
+  call('mdlm_gemm_bf16', A.data_ptr(), A.stride(0), W.data_ptr(), _p(bias),
+       C.data_ptr(), ldc, dt_c, M, N, K, epilogue, _p(gate), _p(residual),
+       rows_per_mod, n_mod, _p(rot_cos), _p(rot_sin), n_heads,
+       _p(m_rows_dev), _stream())
+  return C
+
+
+def attn_fwd(q, k, vt, out, n_seq, H, L, n_seq_dev=None):
+  call('mdlm_attn_fwd', q.data_ptr(), k.data_ptr(), vt.data_ptr(),
+       out.data_ptr(), n_seq, H, L, _p(n_seq_dev), _stream())
+  return out
