@@ -38,17 +38,23 @@ const char* mdlm_last_error_string(void);
  * Masked rows (xt == mask_index): logit - logsumexp with the mask column
  * shifted by -1e6; other rows: -1e6 everywhere, 0 at xt.  `logits` is not
  * modified (the reference mutates its mask column in place; callers that
- * rely on that see the same values through the returned tensor). */
+ * rely on that see the same values through the returned tensor).
+ * as_probs != 0 writes exp(log-prob) instead (the `.exp()` of
+ * diffusion.py:602 fused in: p_x0 for _ddpm_caching_update). */
 int mdlm_subs_logprobs(const void* logits, int64_t ld_in, int dtype_in,
                        const int64_t* xt, void* out, int64_t ld_out,
                        int dtype_out, int64_t rows, int V, int mask_index,
-                       void* stream);
+                       int as_probs, void* stream);
 
 /* Row log-sum-exp of the SUBS-shifted logits (diffusion.py:263-268) for the
- * masked rows only; rows with xt != mask get lse = 0 and are not read. */
+ * masked rows only; rows with xt != mask get lse = 0 and are not read.
+ * sample_map/L/n_rows_dev (optional, may be NULL/any/NULL): visit only the
+ * rows of the listed samples -- launch row r < *n_rows_dev handles row
+ * sample_map[r / L] * L + r % L of logits, xt and lse. */
 int mdlm_subs_row_lse(const void* logits, int64_t ld, int dtype,
                       const int64_t* xt, float* lse, int64_t rows, int V,
-                      int mask_index, void* stream);
+                      int mask_index, const int32_t* sample_map, int L,
+                      const int32_t* n_rows_dev, void* stream);
 
 /* (a') noise removal: argmax_v SUBS(logits), diffusion.py:690-697 / 982.
  * Unmasked rows return xt; masked rows the best non-mask column (first index
@@ -137,19 +143,24 @@ int mdlm_linear_f32(const float* in, const float* W, const float* bias,
 
 /* LayerNorm (no affine, eps 1e-5, fp32) * weight, then modulate_fused,
  * dit.py:126-134 + 74-78: out = LN(x)*w*(1+scale)+shift -> bf16.
- * shift/scale (n_mod, D) fp32; row r uses modulation row (r / rows_per_mod)
- * % n_mod (n_mod == 1: batch-invariant conditioning). */
+ * shift/scale: n_mod rows of D fp32, mod_ld elements apart; row r uses
+ * modulation row (r / rows_per_mod) % n_mod (n_mod == 1: batch-invariant
+ * conditioning, as with time_conditioning=False). */
 int mdlm_ln_modulate(const float* x, const float* ln_w, const float* shift,
                      const float* scale, void* out_bf16, int64_t rows, int D,
-                     int64_t rows_per_mod, int n_mod,
+                     int64_t rows_per_mod, int n_mod, int64_t mod_ld,
                      const int32_t* n_rows_dev, void* stream);
 
 /* nn.Linear on bf16 MFMA, dit.py:220-228, 256, 277, 306/320:
  * C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  A bf16 (lda), W bf16 contiguous.
  * Requires K % 64 == 0, M % 128 == 0.  bias (N) fp32 or NULL.
- *   STORE          : C (ldc, dtype_c) = acc + bias
+ *   STORE          : C (ldc, dtype_c) = acc + bias.  out_sample_map (optional):
+ *                    output row r is written to row out_sample_map[r / L] * L
+ *                    + r % L with L = rows_per_mod (scatter of compacted samples
+ *                    back into a per-sample logits cache).
  *   BIAS_GELU      : C bf16 = gelu_tanh(acc + bias)            (dit.py:225-228)
- *   GATE_RESIDUAL  : C fp32 = residual + gate[row/rows_per_mod] * (acc + bias)
+ *   GATE_RESIDUAL  : C fp32 = residual + gate[(row/rows_per_mod) % n_mod] *
+ *                    (acc + bias); gate rows mod_ld elements apart
  *                    (bias_dropout_add_scale, eval mode, dit.py:20-34)
  *   QKV_ROTARY     : N = 3*H*64; q,k get the NeoX rotary (dit.py:112-115) with
  *                    rot_cos/rot_sin (L,32) fp32 and are written head-major
@@ -161,13 +172,14 @@ int mdlm_ln_modulate(const float* x, const float* ln_w, const float* shift,
 int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
                    void* C, int64_t ldc, int dtype_c, int64_t M, int N, int K,
                    int epilogue, const float* gate, const float* residual,
-                   int64_t rows_per_mod, int n_mod, const float* rot_cos,
-                   const float* rot_sin, int n_heads,
-                   const int32_t* m_rows_dev, void* stream);
+                   int64_t rows_per_mod, int n_mod, int64_t mod_ld,
+                   const float* rot_cos, const float* rot_sin, int n_heads,
+                   const int32_t* m_rows_dev, const int32_t* out_sample_map,
+                   void* stream);
 
 /* Bidirectional attention, dit.py:265-275 (flash_attn_varlen_qkvpacked_func,
  * equal lengths, no dropout, softmax scale 1/sqrt(64)): q,k (n_seq,H,L,64)
- * bf16, vt (n_seq,H,64,L) bf16 -> out (n_seq*L, H*64) bf16.  L % 64 == 0. */
+ * bf16, vt (n_seq,H,64,L) bf16 -> out (n_seq*L, H*64) bf16.  L % 128 == 0. */
 int mdlm_attn_fwd(const void* q, const void* k, const void* vt, void* out,
                   int n_seq, int H, int L, const int32_t* n_seq_dev,
                   void* stream);
@@ -176,10 +188,13 @@ int mdlm_attn_fwd(const void* q, const void* k, const void* vt, void* out,
 
 /* Build the active-sample list from per-sample `changed` flags (device side
  * replacement for the host decision at diffusion.py:682-685): active[0..n)
- * = ascending sample ids with changed != 0, *n_active = n, n_rows = n*L. */
+ * = ascending sample ids with changed != 0, *n_active = n, *n_rows = n*L.
+ * all_or_nothing != 0 reproduces the reference policy literally: if any
+ * sample changed, every sample is listed.  nfe_accum (optional int64):
+ * += n (backbone evaluations, in samples). */
 int mdlm_compact_active(const int32_t* changed, int32_t* active,
                         int32_t* n_active, int32_t* n_rows, int B, int L,
-                        void* stream);
+                        int all_or_nothing, int64_t* nfe_accum, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,8 +17,8 @@ _vp, _i64, _i32, _u64, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_do
 
 # name -> argtypes; every function returns int.
 SIGNATURES = {
-  'mdlm_subs_logprobs': [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp],
-  'mdlm_subs_row_lse': [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp],
+  'mdlm_subs_logprobs': [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _i32, _vp],
+  'mdlm_subs_row_lse': [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp],
   'mdlm_subs_argmax': [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp],
   'mdlm_ddpm_cache_update': [_vp, _i64, _i32, _vp, _vp, _dbl, _vp, _u64, _u64,
                              _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -32,11 +32,12 @@ SIGNATURES = {
   'mdlm_embed_rows': [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _vp],
   'mdlm_timestep_embedding': [_vp, _vp, _i32, _i32, _vp],
   'mdlm_linear_f32': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
-  'mdlm_ln_modulate': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp],
+  'mdlm_ln_modulate': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i64, _vp, _vp],
   'mdlm_gemm_bf16': [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32,
-                     _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp],
+                     _i32, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp,
+                     _vp],
   'mdlm_attn_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
-  'mdlm_compact_active': [_vp, _vp, _vp, _vp, _i32, _i32, _vp],
+  'mdlm_compact_active': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
 }
 
 _lib = None

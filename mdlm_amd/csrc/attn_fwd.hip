@@ -1,0 +1,209 @@
+// Bidirectional flash attention forward for the DiT block (gfx950), head_dim 64.
+// Replaces flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, L, 0.0,
+// causal=False) at models/dit.py:265-275 (equal-length sequences, softmax
+// scale 1/sqrt(64), no mask, no dropout).
+//
+// Inputs come from the QKV GEMM epilogue: q,k head-major (n_seq,H,L,64) and v
+// already transposed vt (n_seq,H,64,L).  One workgroup = 4 waves = 128 query
+// rows of one (sequence, head); each wave owns 32 query rows.  K / V^T tiles of
+// 64 keys are staged global->LDS by 16-byte LDS-DMA, double buffered, with the
+// 16-byte chunk index XOR-swizzled by (row>>1)&7 (conflict-free ds_read_b128
+// for the 32x32x16 A-operand map).
+//
+// MFMA plan (v_mfma_f32_32x32x16_bf16):
+//   S^T[key,q] = K[key,:] . Q[q,:]      (A = K rows, B = Q rows)  -> a lane holds
+//                one query column and 16 keys per 32-key tile, so the softmax
+//                row statistics are in-lane + one cross-half exchange;
+//   O^T[d,q]  += V^T[d,key] . P^T[key,q] (A = V^T rows, B = the S^T accumulator
+//                re-packed to bf16 in place: no LDS round trip).  The K rows fed
+//                to A-row r are permuted (bits 2,3 of r swapped) so that the keys
+//                each lane needs from V^T are 8 contiguous elements.
+#include "common.h"
+
+namespace mdlm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int AT = 256;          // threads: 4 waves x 32 query rows
+constexpr int QB = 128;          // query rows per workgroup
+constexpr int KB = 64;           // keys per tile
+constexpr int HD = 64;           // head dim
+constexpr int KV_TILE = KB * HD * 2;  // 8 KiB
+
+#define GLDS16(gptr, lptr) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+__global__ __launch_bounds__(AT, 2) void attn_fwd_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+    const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, int H, int L,
+    const int32_t* __restrict__ n_seq_dev) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE];  // K0 K1 V0 V1
+  const int qblocks = L / QB;
+  const int bid = blockIdx.x;
+  const int qb = bid % qblocks;
+  const int bh = bid / qblocks;        // seq * H + head
+  const int seq = bh / H, head = bh - seq * H;
+  if (n_seq_dev && seq >= *n_seq_dev) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int q0 = qb * QB + wid * 32;
+
+  const bf16_t* qp = q + ((int64_t)bh * L + q0 + r) * HD;
+  const bf16_t* kp = k + (int64_t)bh * L * HD;
+  const bf16_t* vp = vt + (int64_t)bh * HD * L;
+
+  // Q fragments: B operand, lane (q=r, half hh) holds Q[q][16*ks + 8*hh + j]
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16 + hh * 8);
+
+  // staging: per tile 8 KiB for K and 8 KiB for V^T = 8 + 8 wave-instructions;
+  // wave w issues chunks {w, w+4}.  chunk c -> tile rows c*8..c*8+7.
+  const int srow = lane >> 3;
+  auto stage = [&](int buf, int key0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = wid + i * 4;
+      const int row = c * 8 + srow;
+      const int logical = (lane & 7) ^ ((row >> 1) & 7);
+      GLDS16(kp + (int64_t)(key0 + row) * HD + logical * 8, smem + buf * KV_TILE + c * 1024);
+      GLDS16(vp + (int64_t)row * L + key0 + logical * 8, smem + (2 + buf) * KV_TILE + c * 1024);
+    }
+  };
+
+  // fragment read offsets.  K: A-row r of key-tile kt2 reads tile row
+  // kt2*32 + pi(r), pi = swap bits 2 and 3; logical chunk ks*2 + hh.
+  const int pr = (r & ~0xC) | ((r & 4) << 1) | ((r & 8) >> 1);
+  int koff[2][4];
+#pragma unroll
+  for (int kt2 = 0; kt2 < 2; ++kt2) {
+    const int row = kt2 * 32 + pr;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      koff[kt2][ks] = row * 128 + (((ks * 2 + hh) ^ ((row >> 1) & 7)) * 16);
+  }
+  // V^T: A-row r of d-tile dt reads tile row d = dt*32 + r; k-step (kt2, s)
+  // needs keys kt2*32 + 16*s + 8*hh + (0..7) = logical chunk kt2*4 + 2*s + hh.
+  int voff[2][4];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    const int row = dt * 32 + r;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)  // c4 = kt2*2 + s
+      voff[dt][c4] = row * 128 + ((((c4 >> 1) * 4 + (c4 & 1) * 2 + hh) ^ ((row >> 1) & 7)) * 16);
+  }
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sc = 0.125f * 1.4426950408889634f;  // softmax scale * log2(e)
+
+  const int NT = L / KB;
+  stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < NT; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < NT) stage(cur ^ 1, (t + 1) * KB);
+    const char* Kt = smem + cur * KV_TILE;
+    const char* Vt = smem + (2 + cur) * KV_TILE;
+
+    // ---- S^T = K Q^T ----------------------------------------------------
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kt2][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kt + koff[kt2][ks]);
+        sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt2], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (per query column; keys in-lane + other half) ----
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sacc[0][e]);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[1][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * sc);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = exp2f(sacc[kt2][e] * sc - m_new);
+        sacc[kt2][e] = p;
+        lsum += p;
+      }
+    l_run = l_run * alpha + lsum;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+    // ---- P^T fragments straight from the accumulators --------------------
+    bf16x8 pf[4];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const int kt2 = c4 >> 1, s = c4 & 1;
+      const uint4 pk = make_uint4(
+        pack_bf16x2(sacc[kt2][8 * s + 0], sacc[kt2][8 * s + 1]),
+        pack_bf16x2(sacc[kt2][8 * s + 2], sacc[kt2][8 * s + 3]),
+        pack_bf16x2(sacc[kt2][8 * s + 4], sacc[kt2][8 * s + 5]),
+        pack_bf16x2(sacc[kt2][8 * s + 6], sacc[kt2][8 * s + 7]));
+      pf[c4] = __builtin_bit_cast(bf16x8, pk);
+    }
+    // ---- O^T += V^T P^T ----------------------------------------------------
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vt + voff[dt][c4]);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c4], oacc[dt], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+
+  // ---- normalise and store O[q, head*64 + d] ------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  bf16_t* op = out + ((int64_t)seq * L + q0 + r) * ((int64_t)H * HD) + head * HD;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d = dt * 32 + 8 * g4 + 4 * hh;
+      *reinterpret_cast<uint2*>(op + d) = make_uint2(
+        pack_bf16x2(oacc[dt][4 * g4 + 0] * inv, oacc[dt][4 * g4 + 1] * inv),
+        pack_bf16x2(oacc[dt][4 * g4 + 2] * inv, oacc[dt][4 * g4 + 3] * inv));
+    }
+}
+
+}  // namespace mdlm
+
+using namespace mdlm;
+
+extern "C" int mdlm_attn_fwd(const void* q, const void* k, const void* vt,
+                             void* out, int n_seq, int H, int L,
+                             const int32_t* n_seq_dev, void* stream) {
+  MDLM_CHECK_ARG(q && k && vt && out, "attn_fwd: null pointer");
+  MDLM_CHECK_ARG(n_seq >= 0 && H > 0 && L > 0 && L % QB == 0, "attn_fwd: L=%d must be a multiple of %d", L, QB);
+  MDLM_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) == 0, "attn_fwd: buffers must be 16-byte aligned");
+  if (n_seq == 0) return 0;
+  const int64_t blocks = (int64_t)n_seq * H * (L / QB);
+  MDLM_CHECK_ARG(blocks < (1ll << 31), "attn_fwd: too many blocks");
+  attn_fwd_kernel<<<(unsigned)blocks, AT, 0, (hipStream_t)stream>>>(
+    (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, L, n_seq_dev);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}

@@ -139,7 +139,7 @@ __device__ __forceinline__ int block_argmax(ArgMax a, float* smv, int* smi) {
 }
 
 // ------------------------------------------------------ (a) SUBS log-probs
-template <typename TI, typename TO>
+template <typename TI, typename TO, bool PROBS>
 __global__ __launch_bounds__(NT) void subs_logprobs_kernel(
     const TI* __restrict__ logits, int64_t ld_in, const int64_t* __restrict__ xt,
     TO* __restrict__ out, int64_t ld_out, int V, int mask) {
@@ -150,19 +150,19 @@ __global__ __launch_bounds__(NT) void subs_logprobs_kernel(
   const int64_t tok = xt[r];
   if (tok != mask) {  // diffusion.py:274-276
     for (int i = threadIdx.x; i < V; i += NT)
-      elem<TO>::store(orow + i, i == tok ? 0.f : NEG_INF);
+      elem<TO>::store(orow + i, i == tok ? (PROBS ? 1.f : 0.f) : (PROBS ? 0.f : NEG_INF));
     return;
   }
   const float lse = subs_row_lse<TI>(row, V, mask, sm);
   for (int i = threadIdx.x; i < V; i += NT) {
     float x = elem<TI>::load(row + i);
     if (i == mask) x += NEG_INF;
-    elem<TO>::store(orow + i, x - lse);
+    elem<TO>::store(orow + i, PROBS ? expf(x - lse) : x - lse);
   }
 }
 
 // vectorised variant: both rows 16-byte aligned, same element type
-template <typename T>
+template <typename T, bool PROBS>
 __global__ __launch_bounds__(NT) void subs_logprobs_vec_kernel(
     const T* __restrict__ logits, int64_t ld_in, const int64_t* __restrict__ xt,
     T* __restrict__ out, int64_t ld_out, int V, int mask) {
@@ -189,11 +189,12 @@ __global__ __launch_bounds__(NT) void subs_logprobs_vec_kernel(
     for (int i = threadIdx.x; i < nvec; i += NT) {
       float f[EPV];
 #pragma unroll
-      for (int k = 0; k < EPV; ++k) f[k] = (i * EPV + k == tok) ? 0.f : NEG_INF;
+      for (int k = 0; k < EPV; ++k)
+        f[k] = (i * EPV + k == tok) ? (PROBS ? 1.f : 0.f) : (PROBS ? 0.f : NEG_INF);
       ov[i] = pack(f);
     }
     for (int i = nvec * EPV + threadIdx.x; i < V; i += NT)
-      elem<T>::store(orow + i, i == tok ? 0.f : NEG_INF);
+      elem<T>::store(orow + i, i == tok ? (PROBS ? 1.f : 0.f) : (PROBS ? 0.f : NEG_INF));
     return;
   }
   const float lse = subs_row_lse<T>(row, V, mask, sm);
@@ -204,23 +205,27 @@ __global__ __launch_bounds__(NT) void subs_logprobs_vec_kernel(
 #pragma unroll
     for (int k = 0; k < EPV; ++k) {
       if (i * EPV + k == mask) f[k] += NEG_INF;
-      f[k] -= lse;
+      f[k] = PROBS ? expf(f[k] - lse) : f[k] - lse;
     }
     ov[i] = pack(f);
   }
   for (int i = nvec * EPV + threadIdx.x; i < V; i += NT) {
     float x = elem<T>::load(row + i);
     if (i == mask) x += NEG_INF;
-    elem<T>::store(orow + i, x - lse);
+    elem<T>::store(orow + i, PROBS ? expf(x - lse) : x - lse);
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(NT) void subs_row_lse_kernel(
     const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ xt,
-    float* __restrict__ lse, int V, int mask) {
+    float* __restrict__ lse, int V, int mask,
+    const int32_t* __restrict__ sample_map, int L,
+    const int32_t* __restrict__ n_rows_dev) {
   __shared__ float sm[9];
-  const int64_t r = blockIdx.x;
+  int64_t r = blockIdx.x;
+  if (n_rows_dev && r >= (int64_t)*n_rows_dev) return;
+  if (sample_map) r = (int64_t)sample_map[r / L] * L + (r % L);
   if (xt[r] != mask) { if (threadIdx.x == 0) lse[r] = 0.f; return; }
   const float v = subs_row_lse<T>(logits + r * ld, V, mask, sm);
   if (threadIdx.x == 0) lse[r] = v;
@@ -431,17 +436,29 @@ __global__ __launch_bounds__(1024) void nll_sums_kernel(
 __global__ void compact_active_kernel(const int32_t* __restrict__ changed,
                                       int32_t* __restrict__ active,
                                       int32_t* __restrict__ n_active,
-                                      int32_t* __restrict__ n_rows, int B, int L) {
+                                      int32_t* __restrict__ n_rows, int B, int L,
+                                      int all_or_nothing,
+                                      int64_t* __restrict__ nfe_accum) {
   // single wave; ordered compaction via ballot, 64 samples per pass
+  bool any = false;
+  if (all_or_nothing) {
+    for (int b0 = 0; b0 < B; b0 += 64) {
+      const int b = b0 + threadIdx.x;
+      any = any || (__ballot(b < B && changed[b] != 0) != 0ull);
+    }
+  }
   int base = 0;
   for (int b0 = 0; b0 < B; b0 += 64) {
     const int b = b0 + threadIdx.x;
-    const bool on = b < B && changed[b] != 0;
+    const bool on = b < B && (any || changed[b] != 0);
     const unsigned long long m = __ballot(on);
     if (on) active[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = b;
     base += __popcll(m);
   }
-  if (threadIdx.x == 0) { *n_active = base; *n_rows = base * L; }
+  if (threadIdx.x == 0) {
+    *n_active = base; *n_rows = base * L;
+    if (nfe_accum) *nfe_accum += base;
+  }
 }
 
 static bool is16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -455,7 +472,7 @@ using namespace mdlm;
 extern "C" int mdlm_subs_logprobs(const void* logits, int64_t ld_in, int dtype_in,
                                   const int64_t* xt, void* out, int64_t ld_out,
                                   int dtype_out, int64_t rows, int V,
-                                  int mask_index, void* stream) {
+                                  int mask_index, int as_probs, void* stream) {
   MDLM_CHECK_ARG(logits && xt && out, "subs_logprobs: null pointer");
   MDLM_CHECK_ARG(rows >= 0 && rows < (1ll << 31) && V > 0 && ld_in >= V && ld_out >= V,
                  "subs_logprobs: bad shape rows=%lld V=%d ld_in=%lld ld_out=%lld",
@@ -468,31 +485,37 @@ extern "C" int mdlm_subs_logprobs(const void* logits, int64_t ld_in, int dtype_i
   const size_t es = dtype_in == MDLM_F32 ? 4 : 2;
   const bool vec = dtype_in == dtype_out && is16(logits) && is16(out) &&
                    (ld_in * es) % 16 == 0 && (ld_out * es) % 16 == 0;
-  if (dtype_in == MDLM_F32 && dtype_out == MDLM_F32) {
-    if (vec) subs_logprobs_vec_kernel<float><<<g, b, 0, ST(stream)>>>((const float*)logits, ld_in, xt, (float*)out, ld_out, V, mask_index);
-    else subs_logprobs_kernel<float, float><<<g, b, 0, ST(stream)>>>((const float*)logits, ld_in, xt, (float*)out, ld_out, V, mask_index);
-  } else if (dtype_in == MDLM_BF16 && dtype_out == MDLM_BF16) {
-    if (vec) subs_logprobs_vec_kernel<bf16_t><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index);
-    else subs_logprobs_kernel<bf16_t, bf16_t><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index);
-  } else if (dtype_in == MDLM_BF16) {
-    subs_logprobs_kernel<bf16_t, float><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (float*)out, ld_out, V, mask_index);
-  } else {
-    subs_logprobs_kernel<float, bf16_t><<<g, b, 0, ST(stream)>>>((const float*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index);
+#define MDLM_SL(P) \
+  if (dtype_in == MDLM_F32 && dtype_out == MDLM_F32) { \
+    if (vec) subs_logprobs_vec_kernel<float, P><<<g, b, 0, ST(stream)>>>((const float*)logits, ld_in, xt, (float*)out, ld_out, V, mask_index); \
+    else subs_logprobs_kernel<float, float, P><<<g, b, 0, ST(stream)>>>((const float*)logits, ld_in, xt, (float*)out, ld_out, V, mask_index); \
+  } else if (dtype_in == MDLM_BF16 && dtype_out == MDLM_BF16) { \
+    if (vec) subs_logprobs_vec_kernel<bf16_t, P><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index); \
+    else subs_logprobs_kernel<bf16_t, bf16_t, P><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index); \
+  } else if (dtype_in == MDLM_BF16) { \
+    subs_logprobs_kernel<bf16_t, float, P><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (float*)out, ld_out, V, mask_index); \
+  } else { \
+    subs_logprobs_kernel<float, bf16_t, P><<<g, b, 0, ST(stream)>>>((const float*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index); \
   }
+  if (as_probs) { MDLM_SL(true) } else { MDLM_SL(false) }
+#undef MDLM_SL
   MDLM_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int mdlm_subs_row_lse(const void* logits, int64_t ld, int dtype,
                                  const int64_t* xt, float* lse, int64_t rows,
-                                 int V, int mask_index, void* stream) {
+                                 int V, int mask_index,
+                                 const int32_t* sample_map, int L,
+                                 const int32_t* n_rows_dev, void* stream) {
   MDLM_CHECK_ARG(logits && xt && lse, "subs_row_lse: null pointer");
   MDLM_CHECK_ARG(rows >= 0 && rows < (1ll << 31) && V > 0 && ld >= V, "subs_row_lse: bad shape");
   MDLM_CHECK_ARG(mask_index >= 0 && mask_index < V, "subs_row_lse: mask_index out of range");
   MDLM_CHECK_ARG(dtype == MDLM_F32 || dtype == MDLM_BF16, "subs_row_lse: bad dtype");
   if (rows == 0) return 0;
-  if (dtype == MDLM_F32) subs_row_lse_kernel<float><<<(unsigned)rows, NT, 0, ST(stream)>>>((const float*)logits, ld, xt, lse, V, mask_index);
-  else subs_row_lse_kernel<bf16_t><<<(unsigned)rows, NT, 0, ST(stream)>>>((const bf16_t*)logits, ld, xt, lse, V, mask_index);
+  MDLM_CHECK_ARG(!sample_map || L > 0, "subs_row_lse: sample_map needs L > 0");
+  if (dtype == MDLM_F32) subs_row_lse_kernel<float><<<(unsigned)rows, NT, 0, ST(stream)>>>((const float*)logits, ld, xt, lse, V, mask_index, sample_map, L, n_rows_dev);
+  else subs_row_lse_kernel<bf16_t><<<(unsigned)rows, NT, 0, ST(stream)>>>((const bf16_t*)logits, ld, xt, lse, V, mask_index, sample_map, L, n_rows_dev);
   MDLM_LAUNCH_CHECK();
   return 0;
 }
@@ -613,9 +636,10 @@ extern "C" int mdlm_nll_sums(const float* nll, const float* attn_mask,
 
 extern "C" int mdlm_compact_active(const int32_t* changed, int32_t* active,
                                    int32_t* n_active, int32_t* n_rows, int B,
-                                   int L, void* stream) {
+                                   int L, int all_or_nothing,
+                                   int64_t* nfe_accum, void* stream) {
   MDLM_CHECK_ARG(changed && active && n_active && n_rows && B >= 0 && L > 0, "compact_active: bad args");
-  compact_active_kernel<<<1, 64, 0, ST(stream)>>>(changed, active, n_active, n_rows, B, L);
+  compact_active_kernel<<<1, 64, 0, ST(stream)>>>(changed, active, n_active, n_rows, B, L, all_or_nothing, nfe_accum);
   MDLM_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,276 @@
+"""Host-side mirror of the reference DiT backbone (models/dit.py) whose forward
+runs entirely on the hand-written HIP kernels of libmdlm_hip.so.
+
+Same constructor, attribute and state-dict layout as `models.dit.DIT`
+(dit.py:324-370): `vocab_embed.embedding`, `sigma_map.mlp.{0,2}`,
+`rotary_emb.inv_freq`, `blocks.i.{norm1,attn_qkv,attn_out,norm2,mlp.0,mlp.2,
+adaLN_modulation}`, `output_layer.{norm_final,linear,adaLN_modulation}` -- a
+reference checkpoint's `backbone.*` entries load with `load_state_dict`.
+
+dtype flow (dit.py under `autocast(bf16)`): residual stream
+fp32, LayerNorm fp32, GEMM/attention operands bf16 with fp32 accumulation,
+logits bf16.  The nn.Linear / nn.Parameter objects below only HOLD weights;
+their torch forward is never called.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import EPI_BIAS_GELU, EPI_GATE_RESIDUAL, EPI_QKV_ROTARY, EPI_STORE
+
+
+def _cfg(config, name):
+  m = config['model'] if isinstance(config, dict) else config.model
+  return m[name] if isinstance(m, dict) else getattr(m, name)
+
+
+class LayerNorm(nn.Module):  # dit.py:126-134 (weight only, no bias)
+  def __init__(self, dim):
+    super().__init__()
+    self.weight = nn.Parameter(torch.ones([dim]))
+    self.dim = dim
+
+
+class TimestepEmbedder(nn.Module):  # dit.py:150-189
+  def __init__(self, hidden_size, frequency_embedding_size=256):
+    super().__init__()
+    self.mlp = nn.Sequential(
+      nn.Linear(frequency_embedding_size, hidden_size, bias=True),
+      nn.SiLU(),
+      nn.Linear(hidden_size, hidden_size, bias=True))
+    self.frequency_embedding_size = frequency_embedding_size
+
+
+class Rotary(nn.Module):  # dit.py:81-104
+  def __init__(self, dim, base=10_000):
+    super().__init__()
+    inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+    self.register_buffer('inv_freq', inv_freq)
+
+
+class DDiTBlock(nn.Module):  # dit.py:214-234
+  def __init__(self, dim, n_heads, cond_dim, mlp_ratio=4, dropout=0.1):
+    super().__init__()
+    self.n_heads = n_heads
+    self.norm1 = LayerNorm(dim)
+    self.attn_qkv = nn.Linear(dim, 3 * dim, bias=False)
+    self.attn_out = nn.Linear(dim, dim, bias=False)
+    self.norm2 = LayerNorm(dim)
+    self.mlp = nn.Sequential(
+      nn.Linear(dim, mlp_ratio * dim, bias=True),
+      nn.GELU(approximate='tanh'),
+      nn.Linear(mlp_ratio * dim, dim, bias=True))
+    self.dropout = dropout
+    self.adaLN_modulation = nn.Linear(cond_dim, 6 * dim, bias=True)
+    self.adaLN_modulation.weight.data.zero_()
+    self.adaLN_modulation.bias.data.zero_()
+
+
+class EmbeddingLayer(nn.Module):  # dit.py:292-299
+  def __init__(self, dim, vocab_dim):
+    super().__init__()
+    self.embedding = nn.Parameter(torch.empty((vocab_dim, dim)))
+    torch.nn.init.kaiming_uniform_(self.embedding, a=math.sqrt(5))
+
+
+class DDitFinalLayer(nn.Module):  # dit.py:302-314
+  def __init__(self, hidden_size, out_channels, cond_dim):
+    super().__init__()
+    self.norm_final = LayerNorm(hidden_size)
+    self.linear = nn.Linear(hidden_size, out_channels)
+    self.linear.weight.data.zero_()
+    self.linear.bias.data.zero_()
+    self.adaLN_modulation = nn.Linear(cond_dim, 2 * hidden_size, bias=True)
+    self.adaLN_modulation.weight.data.zero_()
+    self.adaLN_modulation.bias.data.zero_()
+
+
+class DIT(nn.Module):
+  """`backbone(indices, sigma) -> logits (B, L, V)` on MI355X kernels."""
+
+  def __init__(self, config, vocab_size: int):
+    super().__init__()
+    self.config = config
+    self.vocab_size = vocab_size
+    self.hidden = _cfg(config, 'hidden_size')
+    self.n_heads = _cfg(config, 'n_heads')
+    self.cond_dim = _cfg(config, 'cond_dim')
+    self.n_blocks = _cfg(config, 'n_blocks')
+    if self.hidden // self.n_heads != 64 or self.hidden % self.n_heads:
+      raise ValueError('mdlm_amd DIT kernels are written for head_dim == 64 '
+                       f'(got hidden {self.hidden}, heads {self.n_heads})')
+    self.vocab_embed = EmbeddingLayer(self.hidden, vocab_size)
+    self.sigma_map = TimestepEmbedder(self.cond_dim)
+    self.rotary_emb = Rotary(self.hidden // self.n_heads)
+    self.blocks = nn.ModuleList([
+      DDiTBlock(self.hidden, self.n_heads, self.cond_dim,
+                dropout=_cfg(config, 'dropout'))
+      for _ in range(self.n_blocks)])
+    self.output_layer = DDitFinalLayer(self.hidden, vocab_size, self.cond_dim)
+    self.scale_by_sigma = _cfg(config, 'scale_by_sigma')
+    self._prep = None   # device-side kernel operands (bf16 weights, tables)
+    self._ws = None     # activation workspace
+
+  # ------------------------------------------------------------ preparation
+  def refresh(self):
+    """Drop cached kernel operands (call after changing weights)."""
+    self._prep = None
+
+  def load_state_dict(self, *a, **k):
+    r = super().load_state_dict(*a, **k)
+    self.refresh()
+    return r
+
+  def _apply(self, fn, *a, **k):
+    r = super()._apply(fn, *a, **k)
+    self._prep = None
+    self._ws = None
+    return r
+
+  def _prepare(self, L):
+    dev = self.vocab_embed.embedding.device
+    if dev.type != 'cuda':
+      raise RuntimeError('mdlm_amd.DIT runs only on an MI355X (cuda device); '
+                         'there is no CPU fallback')
+    if self._prep is not None and self._prep['L'] == L:
+      return self._prep
+    bf = torch.bfloat16
+
+    def w16(lin):
+      return lin.weight.detach().to(bf).contiguous()
+
+    def f32(t):
+      return t.detach().float().contiguous()
+    p = {'L': L}
+    p['embed'] = f32(self.vocab_embed.embedding)
+    p['blocks'] = []
+    for blk in self.blocks:
+      p['blocks'].append(dict(
+        n1=f32(blk.norm1.weight), n2=f32(blk.norm2.weight),
+        qkv=w16(blk.attn_qkv), out=w16(blk.attn_out),
+        fc1=w16(blk.mlp[0]), b1=f32(blk.mlp[0].bias),
+        fc2=w16(blk.mlp[2]), b2=f32(blk.mlp[2].bias),
+        ada_w=f32(blk.adaLN_modulation.weight),
+        ada_b=f32(blk.adaLN_modulation.bias)))
+    ol = self.output_layer
+    p['final'] = dict(n=f32(ol.norm_final.weight), w=w16(ol.linear),
+                      b=f32(ol.linear.bias),
+                      ada_w=f32(ol.adaLN_modulation.weight),
+                      ada_b=f32(ol.adaLN_modulation.bias))
+    sm = self.sigma_map.mlp
+    p['sm'] = (f32(sm[0].weight), f32(sm[0].bias), f32(sm[2].weight),
+               f32(sm[2].bias))
+    # rotary tables (dit.py:90-104), cast to bf16 like dit.py:264
+    t = torch.arange(L, device=dev).float()
+    freqs = torch.einsum('i,j->ij', t, self.rotary_emb.inv_freq.float())
+    p['cos'] = freqs.cos().to(bf).float().contiguous()
+    p['sin'] = freqs.sin().to(bf).float().contiguous()
+    p['cond0'] = None
+    self._prep = p
+    return p
+
+  def _workspace(self, M):
+    if self._ws is not None and self._ws['M'] >= M:
+      return self._ws
+    dev = self.vocab_embed.embedding.device
+    D = self.hidden
+    bf = torch.bfloat16
+    self._ws = dict(
+      M=M,
+      x=torch.empty(M, D, dtype=torch.float32, device=dev),
+      h=torch.empty(M, D, dtype=bf, device=dev),
+      qkv=torch.empty(3 * M * D, dtype=bf, device=dev),
+      ao=torch.empty(M, D, dtype=bf, device=dev),
+      mh=torch.empty(M, 4 * D, dtype=bf, device=dev))
+    return self._ws
+
+  # ------------------------------------------------------------ conditioning
+  def _conditioning(self, p, sigma):
+    """c = silu(sigma_map(sigma)) (dit.py:361) and every adaLN vector
+    (dit.py:249-250, 318).  Returns a list of (n_mod, 6D) per block + (n_mod,
+    2D) for the final layer."""
+    te = ops.timestep_embedding(sigma.float().contiguous(),
+                                self.sigma_map.frequency_embedding_size)
+    w0, b0, w2, b2 = p['sm']
+    hcond = ops.linear_f32(te, w0, b0, act_out=1)
+    c = ops.linear_f32(hcond, w2, b2, act_out=1)
+    mods = [ops.linear_f32(c, bp['ada_w'], bp['ada_b']) for bp in p['blocks']]
+    mods.append(ops.linear_f32(c, p['final']['ada_w'], p['final']['ada_b']))
+    return mods
+
+  def conditioning(self, p, sigma, sigma_is_zero):
+    if sigma_is_zero:
+      # time_conditioning=False: sigma is zeroed (diffusion.py:307-308), so
+      # the conditioning is one constant vector per model.
+      if p['cond0'] is None:
+        z = torch.zeros(1, device=p['embed'].device)
+        p['cond0'] = self._conditioning(p, z)
+      return p['cond0'], 1
+    return self._conditioning(p, sigma), sigma.shape[0]
+
+  # ------------------------------------------------------------------ forward
+  def run(self, indices, sigma, logits_out, sigma_is_zero=False, active=None,
+          n_active_dev=None, n_rows_dev=None, n_max=None):
+    """Run the backbone.  `indices` (B, L) int64.  `logits_out`: (B, L, V)
+    bf16/fp32 view (padded leading dimension allowed).  If `active` (int32
+    device list) is given, only the listed samples are evaluated (compacted
+    into rows 0..n*L of the workspace) and their logits are scattered to
+    logits_out[active[i]]; n_active_dev / n_rows_dev are device counters and
+    n_max the launch bound."""
+    B, L = indices.shape
+    p = self._prepare(L)
+    D, H = self.hidden, self.n_heads
+    n_seq = B if n_max is None else n_max
+    M = n_seq * L
+    ws = self._workspace(M)
+    x, h, qkv, ao, mh = ws['x'][:M], ws['h'][:M], ws['qkv'], ws['ao'][:M], ws['mh'][:M]
+    mods, n_mod = self.conditioning(p, sigma, sigma_is_zero)
+    if n_mod != 1 and active is not None:
+      raise RuntimeError('active-sample compaction needs batch-invariant '
+                         'conditioning (time_conditioning=False)')
+    ld6, ld2 = 6 * D, 2 * D
+    ops.embed_rows(p['embed'], indices, x, sample_map=active, L=L,
+                   n_rows_dev=n_rows_dev)
+    q_ = qkv[:M * D]
+    k_ = qkv[M * D:2 * M * D]
+    vt_ = qkv[2 * M * D:3 * M * D]
+    for bp, mod in zip(p['blocks'], mods):
+      # chunk order dit.py:249-250: shift_msa, scale_msa, gate_msa, shift_mlp,
+      # scale_mlp, gate_mlp
+      ops.ln_modulate(x, bp['n1'], mod[:, 0:D], mod[:, D:2 * D], h, L, n_mod,
+                      ld6, n_rows_dev)
+      ops.gemm_bf16(h, bp['qkv'], qkv, EPI_QKV_ROTARY, rows_per_mod=L,
+                    rot_cos=p['cos'], rot_sin=p['sin'], n_heads=H,
+                    m_rows_dev=n_rows_dev, ldc=0, M=M)
+      ops.attn_fwd(q_, k_, vt_, ao, n_seq, H, L, n_seq_dev=n_active_dev)
+      ops.gemm_bf16(ao, bp['out'], x, EPI_GATE_RESIDUAL, gate=mod[:, 2 * D:3 * D],
+                    residual=x, rows_per_mod=L, n_mod=n_mod, mod_ld=ld6,
+                    m_rows_dev=n_rows_dev, M=M)
+      ops.ln_modulate(x, bp['n2'], mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D], h,
+                      L, n_mod, ld6, n_rows_dev)
+      ops.gemm_bf16(h, bp['fc1'], mh, EPI_BIAS_GELU, bias=bp['b1'],
+                    m_rows_dev=n_rows_dev, M=M)
+      ops.gemm_bf16(mh, bp['fc2'], x, EPI_GATE_RESIDUAL, bias=bp['b2'],
+                    gate=mod[:, 5 * D:6 * D], residual=x, rows_per_mod=L,
+                    n_mod=n_mod, mod_ld=ld6, m_rows_dev=n_rows_dev, M=M)
+    fm = mods[-1]
+    ops.ln_modulate(x, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod,
+                    ld2, n_rows_dev)
+    assert logits_out.shape[-1] == self.vocab_size
+    ops.gemm_bf16(h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
+                  rows_per_mod=L, m_rows_dev=n_rows_dev, out_sample_map=active,
+                  ldc=logits_out.stride(-2), M=M)
+    return logits_out
+
+  def forward(self, indices, sigma, out=None, out_dtype=torch.bfloat16):
+    """dit.py:359-370: logits (B, L, V) (bf16 like the reference under
+    autocast).  The result is a view of a row-padded buffer."""
+    if not indices.is_cuda:
+      raise RuntimeError('mdlm_amd.DIT.forward: expected CUDA/ROCm tensors; '
+                         'there is no CPU fallback')
+    B, L = indices.shape
+    if out is None:
+      out = ops.alloc_logits(B, L, self.vocab_size, out_dtype, indices.device)
+    return self.run(indices.contiguous(), sigma, out)

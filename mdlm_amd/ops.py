@@ -60,7 +60,8 @@ def alloc_logits(B, L, V, dtype=torch.bfloat16, device='cuda'):
 
 
 # ------------------------------------------------------------------ sampler
-def subs_logprobs(logits, xt, mask_index, out=None, out_dtype=None):
+def subs_logprobs(logits, xt, mask_index, out=None, out_dtype=None,
+                  as_probs=False):
   lg, rows, V, ld = _rows2d(logits, 'logits')
   xt = _dev(xt, 'xt', torch.int64).contiguous()
   assert xt.numel() == rows
@@ -74,17 +75,20 @@ def subs_logprobs(logits, xt, mask_index, out=None, out_dtype=None):
   o, orows, oV, old = _rows2d(out, 'out')
   assert orows == rows and oV == V
   call('mdlm_subs_logprobs', lg.data_ptr(), ld, _DT[lg.dtype], xt.data_ptr(),
-       o.data_ptr(), old, _DT[o.dtype], rows, V, int(mask_index), _stream())
+       o.data_ptr(), old, _DT[o.dtype], rows, V, int(mask_index),
+       int(bool(as_probs)), _stream())
   return out
 
 
-def subs_row_lse(logits, xt, mask_index, out=None):
+def subs_row_lse(logits, xt, mask_index, out=None, sample_map=None, L=0,
+                 n_rows_dev=None):
   lg, rows, V, ld = _rows2d(logits, 'logits')
   xt = _dev(xt, 'xt', torch.int64).contiguous()
   if out is None:
-    out = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    out = torch.zeros(rows, dtype=torch.float32, device=logits.device)
   call('mdlm_subs_row_lse', lg.data_ptr(), ld, _DT[lg.dtype], xt.data_ptr(),
-       out.data_ptr(), rows, V, int(mask_index), _stream())
+       out.data_ptr(), rows, V, int(mask_index), _p(sample_map), int(L),
+       _p(n_rows_dev), _stream())
   return out
 
 
@@ -197,10 +201,11 @@ def nll_sums(nll, attn_mask=None, sums=None):
   return sums
 
 
-def compact_active(changed, active, n_active, n_rows, L):
+def compact_active(changed, active, n_active, n_rows, L, all_or_nothing=False,
+                   nfe_accum=None):
   call('mdlm_compact_active', changed.data_ptr(), active.data_ptr(),
        n_active.data_ptr(), n_rows.data_ptr(), changed.numel(), int(L),
-       _stream())
+       int(bool(all_or_nothing)), _p(nfe_accum), _stream())
 
 
 # ---------------------------------------------------------------- DiT ops
@@ -231,19 +236,21 @@ def linear_f32(x, W, bias, act_in=0, act_out=0):
   return out
 
 
-def ln_modulate(x, ln_w, shift, scale, out, rows_per_mod, n_rows_dev=None):
+def ln_modulate(x, ln_w, shift, scale, out, rows_per_mod, n_mod=1, mod_ld=0,
+                n_rows_dev=None):
+  """shift/scale: tensors (views allowed) whose row m starts m*mod_ld elements
+  after data_ptr()."""
   rows, D = x.shape
-  n_mod = shift.shape[0]
-  assert shift.shape == scale.shape == (n_mod, D)
   call('mdlm_ln_modulate', x.data_ptr(), ln_w.data_ptr(), shift.data_ptr(),
-       scale.data_ptr(), out.data_ptr(), rows, D, rows_per_mod, n_mod,
-       _p(n_rows_dev), _stream())
+       scale.data_ptr(), out.data_ptr(), rows, D, int(rows_per_mod), int(n_mod),
+       int(mod_ld), _p(n_rows_dev), _stream())
   return out
 
 
 def gemm_bf16(A, W, C, epilogue=_lib.EPI_STORE, bias=None, gate=None,
-              residual=None, rows_per_mod=1, n_mod=1, rot_cos=None,
-              rot_sin=None, n_heads=0, m_rows_dev=None, ldc=None, M=None):
+              residual=None, rows_per_mod=1, n_mod=1, mod_ld=0, rot_cos=None,
+              rot_sin=None, n_heads=0, m_rows_dev=None, out_sample_map=None,
+              ldc=None, M=None):
   """C = epilogue(A @ W^T); see include/mdlm_hip.h (mdlm_gemm_bf16)."""
   if M is None:
     M = A.shape[0]
@@ -252,16 +259,16 @@ def gemm_bf16(A, W, C, epilogue=_lib.EPI_STORE, bias=None, gate=None,
   assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16
   assert W.shape[1] == K and W.is_contiguous() and A.stride(1) == 1
   if ldc is None:
-    ldc = C.stride(0) if C.dim() == 2 else 0
-  dt_c = _DT[C.dtype]
+    ldc = C.stride(-2) if C.dim() >= 2 else 0
   call('mdlm_gemm_bf16', A.data_ptr(), A.stride(0), W.data_ptr(), _p(bias),
-       C.data_ptr(), ldc, dt_c, M, N, K, epilogue, _p(gate), _p(residual),
-       rows_per_mod, n_mod, _p(rot_cos), _p(rot_sin), n_heads,
-       _p(m_rows_dev), _stream())
+       C.data_ptr(), int(ldc), _DT[C.dtype], int(M), N, K, int(epilogue),
+       _p(gate), _p(residual), int(rows_per_mod), int(n_mod), int(mod_ld),
+       _p(rot_cos), _p(rot_sin), int(n_heads), _p(m_rows_dev),
+       _p(out_sample_map), _stream())
   return C
 
 
 def attn_fwd(q, k, vt, out, n_seq, H, L, n_seq_dev=None):
   call('mdlm_attn_fwd', q.data_ptr(), k.data_ptr(), vt.data_ptr(),
-       out.data_ptr(), n_seq, H, L, _p(n_seq_dev), _stream())
+       out.data_ptr(), int(n_seq), int(H), int(L), _p(n_seq_dev), _stream())
   return out

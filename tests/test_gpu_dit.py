@@ -1,0 +1,272 @@
+"""GPU parity tests for the DiT-side kernels (d): LN+modulate, bf16 MFMA GEMM
+with its epilogues, rotary, attention, and the whole backbone, against the
+CPU oracle (fp32).  bf16 tolerance per north_star: 2e-2."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mdlm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+  assert torch.cuda.is_available()
+  from mdlm_amd import ops as _ops
+  return _ops
+
+
+def _bf(t):
+  return t.to(torch.bfloat16)
+
+
+def _rel(a, b):
+  return ((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-12)).item()
+
+
+def test_small_ops(ops):
+  torch.manual_seed(0)
+  # timestep embedding (dit.py:162-184)
+  t = torch.tensor([0.0, 0.3, 2.0, 7.5])
+  te = ops.timestep_embedding(t.cuda(), 256).cpu()
+  ref = orc.timestep_embedding(t, 256)
+  assert (te - ref).abs().max().item() < 1e-5
+  assert torch.equal(te[0], torch.cat([torch.ones(128), torch.zeros(128)]))
+  # conditioning linears
+  x = torch.randn(3, 40); W = torch.randn(17, 40); b = torch.randn(17)
+  y = ops.linear_f32(x.cuda(), W.cuda(), b.cuda(), act_in=1, act_out=1).cpu()
+  ref = F.silu(F.linear(F.silu(x), W, b))
+  assert (y - ref).abs().max().item() < 1e-4
+  # embedding gather with a sample map and a device-side live-row count
+  table = torch.randn(50, 64)
+  idx = torch.randint(0, 50, (4, 8))
+  out = torch.zeros(32, 64).cuda()
+  amap = torch.tensor([2, 0, 3, 1], dtype=torch.int32).cuda()
+  nrows = torch.tensor([16], dtype=torch.int32).cuda()
+  ops.embed_rows(table.cuda(), idx.cuda(), out, sample_map=amap, L=8, n_rows_dev=nrows)
+  ref = table[idx[[2, 0]].reshape(-1)]
+  assert torch.equal(out[:16].cpu(), ref)
+  assert (out[16:] == 0).all()
+
+
+@pytest.mark.parametrize('D', [128, 768, 1024])
+def test_ln_modulate(ops, D):
+  torch.manual_seed(1)
+  B, L = 3, 64
+  x = torch.randn(B * L, D) * 2 + 0.5
+  w = 1 + 0.1 * torch.randn(D)
+  mod = torch.randn(B, 6 * D) * 0.5
+  out = torch.empty(B * L, D, dtype=torch.bfloat16, device='cuda')
+  dm = mod.cuda()
+  ops.ln_modulate(x.cuda(), w.cuda(), dm[:, D:2 * D], dm[:, 3 * D:4 * D], out, L,
+                  n_mod=B, mod_ld=6 * D)
+  ln = orc.layer_norm_w(x.view(B, L, D), w)
+  ref = orc.modulate(ln, mod[:, None, D:2 * D], mod[:, None, 3 * D:4 * D]).view(B * L, D)
+  err = (out.float().cpu() - ref).abs()
+  assert (err <= 2e-2 * ref.abs().clamp(min=1.0)).all()
+  # batch-invariant conditioning (n_mod = 1)
+  ops.ln_modulate(x.cuda(), w.cuda(), dm[1:2, D:2 * D], dm[1:2, 0:D], out, L,
+                  n_mod=1, mod_ld=6 * D)
+  ref = orc.modulate(ln, mod[1, None, None, D:2 * D], mod[1, None, None, 0:D]).view(B * L, D)
+  err = (out.float().cpu() - ref).abs()
+  assert (err <= 2e-2 * ref.abs().clamp(min=1.0)).all()
+
+
+def _gemm_ref(A, W, bias=None):
+  y = _bf(A).float() @ _bf(W).float().t()
+  return y if bias is None else y + bias
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 384, 128), (128, 1000, 192),
+                                   (384, 2304, 768), (128, 777, 768)])
+def test_gemm_store(ops, M, N, K):
+  from mdlm_amd._lib import EPI_STORE
+  torch.manual_seed(2)
+  A = torch.randn(M, K); W = torch.randn(N, K) * 0.1; bias = torch.randn(N)
+  ref = _gemm_ref(A, W, bias)
+  dA, dW = _bf(A).cuda(), _bf(W).cuda()
+  C = torch.zeros(M, N, device='cuda')
+  ops.gemm_bf16(dA, dW, C, EPI_STORE, bias=bias.cuda())
+  assert _rel(C.cpu(), ref) < 1e-5
+  assert (C.cpu() - ref).abs().max().item() < 1e-3
+  # bf16 output into a padded leading dimension
+  ld = (N + 127) // 128 * 128
+  Cb = torch.zeros(M, ld, dtype=torch.bfloat16, device='cuda')
+  ops.gemm_bf16(dA, dW, Cb[:, :N], EPI_STORE, bias=bias.cuda())
+  assert ((Cb[:, :N].float().cpu() - ref).abs() <= 2e-2 * ref.abs().clamp(min=1.0)).all()
+  assert (Cb[:, N:] == 0).all()  # nothing written past column N
+  # unaligned ldc (N odd multiple) falls back to scalar stores
+  Cu = torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
+  ops.gemm_bf16(dA, dW, Cu, EPI_STORE, bias=bias.cuda())
+  assert torch.equal(Cu, Cb[:, :N])
+
+
+def test_gemm_identity_asymmetric(ops):
+  """A = I with an asymmetric W catches row/col swaps in the C write."""
+  from mdlm_amd._lib import EPI_STORE
+  M = K = 128; N = 256
+  A = torch.eye(M, K)
+  W = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 5 % 7).float() % 64
+  C = torch.zeros(M, N, device='cuda')
+  ops.gemm_bf16(_bf(A).cuda(), _bf(W).cuda(), C, EPI_STORE)
+  assert torch.equal(C.cpu(), _bf(W).float().t())
+
+
+def test_gemm_live_rows_and_scatter(ops):
+  from mdlm_amd._lib import EPI_STORE
+  torch.manual_seed(3)
+  L, B, N, K = 128, 4, 320, 64
+  A = torch.randn(B * L, K); W = torch.randn(N, K)
+  ref = _gemm_ref(A, W)
+  C = torch.full((B * L, N), -5.0, device='cuda')
+  live = torch.tensor([2 * L], dtype=torch.int32).cuda()
+  amap = torch.tensor([3, 1, 0, 0], dtype=torch.int32).cuda()
+  ops.gemm_bf16(_bf(A).cuda(), _bf(W).cuda(), C, EPI_STORE, rows_per_mod=L,
+                m_rows_dev=live, out_sample_map=amap)
+  Cc = C.cpu()
+  assert _rel(Cc[3 * L:4 * L], ref[0:L]) < 1e-5      # compact sample 0 -> slot 3
+  assert _rel(Cc[1 * L:2 * L], ref[L:2 * L]) < 1e-5  # compact sample 1 -> slot 1
+  assert (Cc[0:L] == -5).all() and (Cc[2 * L:3 * L] == -5).all()
+
+
+def test_gemm_gelu_and_gate_residual(ops):
+  from mdlm_amd._lib import EPI_BIAS_GELU, EPI_GATE_RESIDUAL
+  torch.manual_seed(4)
+  B, L, N, K = 2, 128, 256, 128
+  M = B * L
+  A = torch.randn(M, K); W = torch.randn(N, K) * 0.2; bias = torch.randn(N)
+  y = _gemm_ref(A, W, bias)
+  Cg = torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
+  ops.gemm_bf16(_bf(A).cuda(), _bf(W).cuda(), Cg, EPI_BIAS_GELU, bias=bias.cuda())
+  ref = F.gelu(y, approximate='tanh')
+  assert ((Cg.float().cpu() - ref).abs() <= 2e-2 * ref.abs().clamp(min=1.0)).all()
+  # gate * (acc + bias) + residual, per-sample gate rows 6N apart, in place
+  mod = torch.randn(B, 6 * N)
+  res = torch.randn(M, N)
+  X = res.clone().cuda()
+  dm = mod.cuda()
+  ops.gemm_bf16(_bf(A).cuda(), _bf(W).cuda(), X, EPI_GATE_RESIDUAL, bias=bias.cuda(),
+                gate=dm[:, 2 * N:3 * N], residual=X, rows_per_mod=L, n_mod=B,
+                mod_ld=6 * N)
+  gate = mod[:, 2 * N:3 * N].repeat_interleave(L, 0)
+  ref = res + gate * y
+  assert (X.cpu() - ref).abs().max().item() < 2e-3
+  # shared gate (n_mod = 1), no bias
+  X = res.clone().cuda()
+  ops.gemm_bf16(_bf(A).cuda(), _bf(W).cuda(), X, EPI_GATE_RESIDUAL,
+                gate=dm[1:2, 0:N], residual=X, rows_per_mod=L, n_mod=1, mod_ld=6 * N)
+  ref = res + mod[1, 0:N][None] * _gemm_ref(A, W)
+  assert (X.cpu() - ref).abs().max().item() < 2e-3
+
+
+def _qkv_ref(h, Wqkv, B, L, H):
+  """bf16 Linear output -> rotary (bf16 cos/sin, fp32 math) -> bf16."""
+  qkv = _bf(_gemm_ref(h, Wqkv)).float().view(B, L, 3, H, 64)
+  cos, sin = orc.rotary_cos_sin(L, 64)
+  rot = orc.apply_rotary_qk(qkv, _bf(cos).float(), _bf(sin).float())
+  return _bf(rot).float()
+
+
+def test_gemm_qkv_rotary_layout(ops):
+  from mdlm_amd._lib import EPI_QKV_ROTARY
+  torch.manual_seed(5)
+  B, L, H = 2, 128, 2
+  D = H * 64
+  M = B * L
+  h = torch.randn(M, D); Wqkv = torch.randn(3 * D, D) * 0.1
+  ref = _qkv_ref(h, Wqkv, B, L, H)            # (B, L, 3, H, 64)
+  cos, sin = orc.rotary_cos_sin(L, 64)
+  out = torch.zeros(3 * M * D, dtype=torch.bfloat16, device='cuda')
+  ops.gemm_bf16(_bf(h).cuda(), _bf(Wqkv).cuda(), out, EPI_QKV_ROTARY, rows_per_mod=L,
+                rot_cos=_bf(cos).float().cuda(), rot_sin=_bf(sin).float().cuda(),
+                n_heads=H, ldc=0)
+  o = out.float().cpu()
+  q = o[:M * D].view(B, H, L, 64)
+  k = o[M * D:2 * M * D].view(B, H, L, 64)
+  vt = o[2 * M * D:].view(B, H, 64, L)
+  tol = lambda a, b: ((a - b).abs() <= 2e-2 * b.abs().clamp(min=1.0)).all()
+  assert tol(q, ref[:, :, 0].permute(0, 2, 1, 3))
+  assert tol(k, ref[:, :, 1].permute(0, 2, 1, 3))
+  assert tol(vt, ref[:, :, 2].permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize('L', [128, 256, 1024])
+def test_attention(ops, L):
+  torch.manual_seed(6)
+  B, H = 2, 3
+  q = torch.randn(B, H, L, 64); k = torch.randn(B, H, L, 64); v = torch.randn(B, H, L, 64)
+  # spike one key against one query so the running max jumps mid-sequence
+  k[0, 0, L // 2 + 5] = q[0, 0, 7] * 3
+  qb, kb, vb = _bf(q), _bf(k), _bf(v)
+  ref = F.scaled_dot_product_attention(qb.float(), kb.float(), vb.float())
+  ref = ref.transpose(1, 2).reshape(B * L, H * 64)
+  out = torch.zeros(B * L, H * 64, dtype=torch.bfloat16, device='cuda')
+  ops.attn_fwd(qb.cuda(), kb.cuda(), vb.transpose(2, 3).contiguous().cuda(), out, B, H, L)
+  err = (out.float().cpu() - ref).abs()
+  assert err.max().item() < 2e-2, err.max().item()
+  assert _rel(out.float().cpu(), ref) < 1e-2
+  # device-side live-sequence count
+  out2 = torch.full_like(out, 9.0)
+  live = torch.tensor([1], dtype=torch.int32).cuda()
+  ops.attn_fwd(qb.cuda(), kb.cuda(), vb.transpose(2, 3).contiguous().cuda(), out2, B, H, L,
+               n_seq_dev=live)
+  assert torch.equal(out2[:L], out[:L]) and (out2[L:] == 9).all()
+
+
+def _make_model(hidden, heads, blocks, cond, V, seed):
+  from mdlm_amd.dit import DIT
+  cfg = {'model': dict(hidden_size=hidden, cond_dim=cond, n_heads=heads,
+                       n_blocks=blocks, dropout=0.1, scale_by_sigma=True)}
+  p = orc.synthetic_dit_params(hidden, heads, blocks, cond, V, seed=seed)
+  m = DIT(cfg, vocab_size=V)
+  sd = dict(p)
+  sd['rotary_emb.inv_freq'] = m.rotary_emb.inv_freq
+  m.load_state_dict(sd)
+  return m.cuda(), p
+
+
+@pytest.mark.parametrize('shape', [(128, 2, 2, 64, 300, 128), (768, 12, 2, 128, 1000, 256)])
+def test_dit_forward_vs_oracle(ops, shape):
+  hidden, heads, blocks, cond, V, L = shape
+  model, p = _make_model(hidden, heads, blocks, cond, V, seed=3)
+  torch.manual_seed(7)
+  B = 2
+  idx = torch.randint(0, V, (B, L))
+  for sigma in (torch.zeros(B), torch.tensor([0.4, 1.7])):
+    ref = orc.dit_forward(p, idx, sigma, heads, blocks)
+    out = model(idx.cuda(), sigma.cuda())
+    assert out.shape == (B, L, V) and out.dtype == torch.bfloat16
+    o = out.float().cpu()
+    assert _rel(o, ref) < 2e-2, _rel(o, ref)
+    # log-probs within the bf16 tolerance
+    lp = torch.log_softmax(o, -1); lr = torch.log_softmax(ref, -1)
+    assert (lp - lr).abs().max().item() < 6e-2
+    assert (lp - lr).abs().mean().item() < 1e-2
+  # constant-conditioning shortcut (sigma zeroed) == general path
+  out0 = model.run(idx.cuda(), torch.zeros(B).cuda(),
+                   ops.alloc_logits(B, L, V), sigma_is_zero=True)
+  out1 = model(idx.cuda(), torch.zeros(B).cuda())
+  assert torch.equal(out0, out1)
+
+
+def test_dit_active_compaction_is_batch_invariant(ops):
+  """Per-sample evaluation must be bit-identical to the full-batch one."""
+  hidden, heads, blocks, cond, V, L = 128, 2, 2, 64, 300, 128
+  model, _ = _make_model(hidden, heads, blocks, cond, V, seed=4)
+  torch.manual_seed(8)
+  B = 5
+  idx = torch.randint(0, V, (B, L)).cuda()
+  z = torch.zeros(B).cuda()
+  full = model.run(idx, z, ops.alloc_logits(B, L, V), sigma_is_zero=True).clone()
+  cache = ops.alloc_logits(B, L, V); cache.fill_(0)
+  active = torch.tensor([4, 1, 2, 0, 0], dtype=torch.int32).cuda()
+  n_act = torch.tensor([3], dtype=torch.int32).cuda()
+  n_rows = torch.tensor([3 * L], dtype=torch.int32).cuda()
+  model.run(idx, z, cache, sigma_is_zero=True, active=active, n_active_dev=n_act,
+            n_rows_dev=n_rows, n_max=B)
+  for b in (4, 1, 2):
+    assert torch.equal(cache[b], full[b])
+  assert (cache[0] == 0).all() and (cache[3] == 0).all()
