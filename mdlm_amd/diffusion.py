@@ -1,0 +1,471 @@
+"""`Diffusion`: drop-in for the hot-path methods of the reference's
+`diffusion.Diffusion` LightningModule (diffusion.py:68-1024), running on the
+MI355X kernels of libmdlm_hip.so.
+
+Kept verbatim from the reference: constructor `(config, tokenizer)`, the
+attributes `mask_index`, `vocab_size`, `neg_infinity`, `sampler`, `T`,
+`time_conditioning`, `parameterization`, `noise`, `backbone`, `ema`, and the
+methods `forward`, `_subs_parameterization`, `_process_sigma`, `q_xt`,
+`_sample_prior`, `_ddpm_caching_update`, `_sample`, `restore_model_and_sample`,
+`sample_subs_guidance`, `restore_model_and_semi_ar_sample`, `_sample_t`,
+`_forward_pass_diffusion`, `_loss`, `_compute_loss`, `validation_step`.
+
+Extensions (keyword-only, allowed by the north star): supplied uniform noise
+`u=` for parity runs; otherwise uniforms come from an in-kernel Philox4x32-10
+stream keyed by (`config.seed` + rank, running offset).
+
+Out of scope (raise): d3pm / sedd parameterisations, `ddpm` / `analytic`
+samplers, T > 0 losses, AR / DiMamba backbones, generative perplexity
+(needs gpt2-large from the hub).  There is no CPU fallback.
+"""
+import itertools
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import dist as mdist
+from . import ops
+from .dit import DIT
+from .ema import ExponentialMovingAverage
+from .noise_schedule import get_noise
+
+try:  # Lightning is optional; the reference derives from L.LightningModule
+  import lightning as L
+  _Base = L.LightningModule
+except Exception:  # pragma: no cover - lightning is absent in this image
+  _Base = torch.nn.Module
+
+LOG2 = math.log(2)
+
+
+@dataclass
+class Loss:  # diffusion.py:37-41
+  loss: torch.FloatTensor
+  nlls: torch.FloatTensor
+  token_mask: torch.FloatTensor
+
+
+class MeanMetrics:
+  """NLL / BPD / Perplexity (diffusion.py:44-65): torchmetrics MeanMetric in
+  float64 -- sums[0] = sum(nll * w), sums[1] = sum(w), accumulated on device by
+  `mdlm_nll_sums`; `compute()` all-reduces the pair over ranks (C3)."""
+
+  def __init__(self, prefix=''):
+    self.prefix = prefix
+    self.sums = None
+
+  def reset(self):
+    self.sums = None
+
+  def update(self, nlls, token_mask):
+    # nlls already carry the mask factor (diffusion.py:908); MeanMetric then
+    # weights by the mask again: sum(nll * w) / sum(w)  (diffusion.py:369-376)
+    if self.sums is None:
+      self.sums = torch.zeros(2, dtype=torch.float64, device=nlls.device)
+    if token_mask is not None:
+      nlls = nlls * token_mask
+    ops.nll_sums(nlls, token_mask, self.sums)
+
+  def compute(self, sync_dist=True):
+    s = self.sums.clone()
+    if sync_dist:
+      mdist.all_reduce_sums(s)
+    mean = (s[0] / s[1]).item()
+    p = self.prefix
+    return {p + 'nll': mean, p + 'bpd': mean / LOG2, p + 'ppl': math.exp(mean)}
+
+
+class Diffusion(_Base):
+  def __init__(self, config, tokenizer):
+    super().__init__()
+    self.config = config
+    self.tokenizer = tokenizer
+    self.vocab_size = self.tokenizer.vocab_size
+    self.sampler = self.config.sampling.predictor
+    self.antithetic_sampling = self.config.training.antithetic_sampling
+    self.importance_sampling = self.config.training.importance_sampling
+    self.change_of_variables = self.config.training.change_of_variables
+    # diffusion.py:85-90
+    if (not hasattr(self.tokenizer, 'mask_token')
+        or self.tokenizer.mask_token is None):
+      self.mask_index = self.vocab_size
+      self.vocab_size += 1
+    else:
+      self.mask_index = self.tokenizer.mask_token_id
+    self.parameterization = self.config.parameterization
+    if self.config.backbone != 'dit':
+      raise ValueError(f'backbone {self.config.backbone!r}: only the DiT '
+                       'backbone is on the mdlm_amd hot path')
+    self.backbone = DIT(self.config, vocab_size=self.vocab_size)
+    self.T = self.config.T
+    self.subs_masking = self.config.subs_masking
+    self.train_metrics = MeanMetrics('train/')
+    self.valid_metrics = MeanMetrics('val/')
+    self.test_metrics = MeanMetrics('test/')
+    self.noise = get_noise(self.config)
+    if self.config.training.ema > 0:
+      self.ema = ExponentialMovingAverage(
+        itertools.chain(self.backbone.parameters(), self.noise.parameters()),
+        decay=self.config.training.ema)
+    else:
+      self.ema = None
+    self.lr = self.config.optim.lr
+    self.sampling_eps = self.config.training.sampling_eps
+    self.time_conditioning = self.config.time_conditioning
+    self.neg_infinity = -1000000.0
+    self._validate_configuration()
+    # Philox stream: key = seed + rank, counter advances with every draw
+    self._rng_seed = mdist.rank_seed(self.config.seed, mdist.env_rank()[0])
+    self._rng_offset = 0
+    self._state = None
+    self.last_nfe = None
+
+  # ---------------------------------------------------------------- helpers
+  def _validate_configuration(self):  # diffusion.py:155-166
+    assert not (self.change_of_variables and self.importance_sampling)
+    if self.parameterization != 'subs':
+      raise NotImplementedError(
+        f'parameterization {self.parameterization!r}: only SUBS (MDLM) is on '
+        'the mdlm_amd hot path')
+    if self.T > 0:
+      raise NotImplementedError('T > 0 (discrete-time d3pm loss) is out of '
+                                'scope for the mdlm_amd hot path')
+    if self.importance_sampling or self.change_of_variables:
+      raise NotImplementedError('importance_sampling / change_of_variables '
+                                'are out of scope')
+
+  @property
+  def device(self):
+    return self.backbone.vocab_embed.embedding.device
+
+  @property
+  def dtype(self):
+    return torch.float32
+
+  def seed_rng(self, seed, offset=0):
+    self._rng_seed, self._rng_offset = int(seed), int(offset)
+
+  def _draw(self, n_counters):
+    off = self._rng_offset
+    self._rng_offset += int(n_counters)
+    return self._rng_seed, off
+
+  def on_load_checkpoint(self, checkpoint):  # diffusion.py:168-170
+    if self.ema and 'ema' in checkpoint:
+      self.ema.load_state_dict(checkpoint['ema'])
+      self.ema.move_shadow_params_to_device(self.device)
+
+  def _params(self):
+    return itertools.chain(self.backbone.parameters(), self.noise.parameters())
+
+  def _ema_swap_in(self):
+    if self.ema:
+      self.ema.store(self._params())
+      self.ema.copy_to(self._params())
+      self.backbone.refresh()
+
+  def _ema_swap_out(self):
+    if self.ema:
+      self.ema.restore(self._params())
+      self.backbone.refresh()
+
+  # ------------------------------------------------------------- SUBS / forward
+  def _subs_parameterization(self, logits, xt):
+    """diffusion.py:261-277 on the fused HIP kernel (a)."""
+    return ops.subs_logprobs(logits, xt, self.mask_index)
+
+  def _process_sigma(self, sigma):  # diffusion.py:301-310
+    if sigma.ndim > 1:
+      sigma = sigma.squeeze(-1)
+    if not self.time_conditioning:
+      sigma = torch.zeros_like(sigma)
+    assert sigma.ndim == 1, sigma.shape
+    return sigma
+
+  def _backbone_logits(self, x, sigma):
+    sigma = self._process_sigma(sigma)
+    out = ops.alloc_logits(x.shape[0], x.shape[1], self.vocab_size,
+                           torch.bfloat16, x.device)
+    return self.backbone.run(x.contiguous(), sigma, out,
+                             sigma_is_zero=not self.time_conditioning)
+
+  def forward(self, x, sigma):
+    """Returns log score (diffusion.py:312-327): SUBS log-probs (B, L, V)."""
+    logits = self._backbone_logits(x, sigma)
+    return self._subs_parameterization(logits=logits, xt=x)
+
+  # ------------------------------------------------------------------ q_xt
+  def q_xt(self, x, move_chance, *, u=None):
+    """diffusion.py:575-586 on kernel (c1)."""
+    seed, off = (0, 0) if u is not None else self._draw((x.numel() + 3) // 4)
+    return ops.q_xt(x, move_chance, self.mask_index, u=u, seed=seed, offset=off)
+
+  def _sample_prior(self, *batch_dims):  # diffusion.py:588-590
+    return self.mask_index * torch.ones(*batch_dims, dtype=torch.int64)
+
+  # --------------------------------------------------------- ddpm_cache update
+  def _ddpm_caching_update(self, x, t, dt, p_x0=None, *, u=None):
+    """diffusion.py:592-610: returns (p_x0, x_next).  p_x0 holds probabilities
+    (B, L, V) and is produced by backbone -> SUBS(+exp) when not supplied."""
+    assert self.config.noise.type == 'loglinear'
+    sigma_t, _ = self.noise(t)
+    if t.ndim > 1:
+      t = t.squeeze(-1)
+    assert t.ndim == 1
+    if p_x0 is None:
+      logits = self._backbone_logits(x, sigma_t)
+      od = (torch.float32 if self.config.sampling.get('p_x0_dtype', 'bf16') == 'fp32'
+            else torch.bfloat16)
+      p_x0 = ops.subs_logprobs(logits, x, self.mask_index, out_dtype=od,
+                               as_probs=True)
+    B, Lq = x.shape
+    seed, off = (0, 0) if u is not None else self._draw(
+      B * Lq * ((self.vocab_size + 3) // 4))
+    x_next = ops.ddpm_cache_update(
+      p_x0, x, t, dt, self.mask_index, u=u, seed=seed, offset=off,
+      fast_math=bool(self.config.sampling.get('fast_math', False)) and u is None)
+    return p_x0, x_next
+
+  # ----------------------------------------------------------------- sampling
+  def _sampler_state(self, B, Lq):
+    st = self._state
+    if st is not None and st['B'] == B and st['L'] == Lq and st['dev'] == self.device:
+      return st
+    dev = self.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    st = dict(
+      B=B, L=Lq, dev=dev,
+      cache=ops.alloc_logits(B, Lq, self.vocab_size, torch.bfloat16, dev),
+      lse=torch.zeros(B * Lq, dtype=torch.float32, device=dev),
+      xa=torch.empty(B, Lq, dtype=torch.int64, device=dev),
+      xb=torch.empty(B, Lq, dtype=torch.int64, device=dev),
+      changed=torch.ones(B, **i32), active=torch.zeros(B, **i32),
+      n_active=torch.zeros(1, **i32), n_rows=torch.zeros(1, **i32),
+      nfe=torch.zeros(1, dtype=torch.int64, device=dev),
+      zeros=torch.zeros(B, dtype=torch.float32, device=dev))
+    self._state = st
+    return st
+
+  def _refresh_cache(self, st, x, sigma=None):
+    """Evaluate the backbone for the samples whose tokens changed since their
+    cached logits were computed (device-side replacement of the host decision
+    at diffusion.py:682-685) and refresh their row lse."""
+    B, Lq = st['B'], st['L']
+    per_sample = (not self.time_conditioning and
+                  self.config.sampling.get('cache_policy', 'sample') != 'none')
+    if per_sample:
+      aon = self.config.sampling.get('cache_policy', 'sample') == 'batch'
+      ops.compact_active(st['changed'], st['active'], st['n_active'],
+                         st['n_rows'], Lq, all_or_nothing=aon,
+                         nfe_accum=st['nfe'])
+      self.backbone.run(x, st['zeros'], st['cache'], sigma_is_zero=True,
+                        active=st['active'], n_active_dev=st['n_active'],
+                        n_rows_dev=st['n_rows'], n_max=B)
+      ops.subs_row_lse(st['cache'], x, self.mask_index, out=st['lse'],
+                       sample_map=st['active'], L=Lq, n_rows_dev=st['n_rows'])
+    else:
+      # time conditioning: sigma changes every step, no caching at all
+      st['nfe'] += B
+      sg = st['zeros'] if sigma is None else self._process_sigma(sigma)
+      self.backbone.run(x, sg, st['cache'],
+                        sigma_is_zero=not self.time_conditioning)
+      ops.subs_row_lse(st['cache'], x, self.mask_index, out=st['lse'])
+
+  def _fused_step(self, st, x, x_next, t_vec, dt, sigma=None):
+    self._refresh_cache(st, x, sigma)
+    B, Lq = st['B'], st['L']
+    seed, off = self._draw(B * Lq * ((self.vocab_size + 3) // 4))
+    ops.subs_ddpm_update(
+      st['cache'], st['lse'], x, t_vec, dt, self.mask_index, seed=seed,
+      offset=off, changed=st['changed'], x_next=x_next,
+      fast_math=bool(self.config.sampling.get('fast_math', False)))
+
+  @torch.no_grad()
+  def _sample(self, num_steps=None, eps=1e-5):
+    """Generate samples from the model (diffusion.py:657-698)."""
+    B = self.config.loader.eval_batch_size
+    Lq = self.config.model.length
+    if self.sampler != 'ddpm_cache':
+      raise NotImplementedError(
+        f'sampler {self.sampler!r}: only ddpm_cache is on the mdlm_amd hot path')
+    if num_steps is None:
+      num_steps = self.config.sampling.steps
+    dev = self.device
+    timesteps = torch.linspace(1, eps, num_steps + 1, device=dev)
+    dt = (1 - eps) / num_steps
+    if not self.config.sampling.get('fused', True):
+      return self._sample_reference_loop(B, Lq, num_steps, timesteps, dt)
+    st = self._sampler_state(B, Lq)
+    x, x_next = st['xa'], st['xb']
+    x.fill_(self.mask_index)
+    st['changed'].fill_(1)
+    st['nfe'].zero_()
+    # t = timesteps[i] * ones(B, 1)  (diffusion.py:675-676), all steps at once
+    t_all = timesteps[:, None].expand(num_steps + 1, B).contiguous()
+    for i in range(num_steps):
+      sigma = self.noise(t_all[i])[0] if self.time_conditioning else None
+      self._fused_step(st, x, x_next, t_all[i], dt, sigma)
+      x, x_next = x_next, x
+    if self.config.sampling.noise_removal:
+      # forward(x, sigma(t_last)).argmax(-1)  (diffusion.py:690-697)
+      sigma = self.noise(t_all[-1])[0] if self.time_conditioning else None
+      self._refresh_cache(st, x, sigma)
+      ops.subs_argmax(st['cache'], x, self.mask_index, out=x_next)
+      x = x_next
+    self.last_nfe = st['nfe']  # device counter; .item() syncs
+    return x.clone()
+
+  def _sample_reference_loop(self, B, Lq, num_steps, timesteps, dt):
+    """The reference loop literally (diffusion.py:666-698): API-level
+    `_ddpm_caching_update` calls and a host-side all-or-nothing cache test."""
+    x = self._sample_prior(B, Lq).to(self.device)
+    p_x0_cache = None
+    nfe = 0
+    for i in range(num_steps):
+      t = timesteps[i] * torch.ones(x.shape[0], 1, device=self.device)
+      nfe += B if p_x0_cache is None else 0
+      p_x0_cache, x_next = self._ddpm_caching_update(x, t, dt, p_x0=p_x0_cache)
+      if (not torch.equal(x_next, x)) or self.time_conditioning:
+        p_x0_cache = None  # Disable caching
+      x = x_next
+    if self.config.sampling.noise_removal:
+      t = timesteps[-1] * torch.ones(x.shape[0], 1, device=self.device)
+      unet_conditioning = self.noise(t)[0]
+      logits = self._backbone_logits(x, unet_conditioning)
+      x = ops.subs_argmax(logits, x, self.mask_index)
+      nfe += B
+    self.last_nfe = torch.tensor([nfe], device=self.device)
+    return x
+
+  def restore_model_and_sample(self, num_steps, eps=1e-5):
+    """diffusion.py:700-719."""
+    self._ema_swap_in()
+    self.backbone.eval()
+    self.noise.eval()
+    samples = self._sample(num_steps=num_steps, eps=eps)
+    self._ema_swap_out()
+    self.backbone.train()
+    self.noise.train()
+    return samples
+
+  # ------------------------------------------------------------------ semi-AR
+  @torch.no_grad()
+  def sample_subs_guidance(self, n_samples, stride_length, num_strides,
+                           dt=0.001):
+    """diffusion.py:957-997: stride-window semi-autoregressive sampling."""
+    dev = self.device
+    Lq = self.config.model.length
+    num_steps = int(1 / dt)
+    st = self._sampler_state(n_samples, Lq)
+    intermediate_tokens = []
+    target = None
+    # t = (1 - i * dt) * ones  (diffusion.py:976), i = 0..num_steps (t = 0 last)
+    steps = torch.arange(num_steps + 1, device=dev, dtype=torch.float32)
+    t_all = ((1 - steps * dt)[:, None] * torch.ones(
+      n_samples, dtype=self.dtype, device=dev)[None]).contiguous()
+    sampling_steps_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    for _ in range(num_strides + 1):
+      x, x_next = st['xa'], st['xb']
+      x.fill_(self.mask_index)
+      if target is not None:
+        x[:, :-stride_length] = target
+      st['changed'].fill_(1)   # p_x0_cache = None
+      for i in range(num_steps + 1):
+        sigma = self.noise(t_all[i])[0] if self.time_conditioning else None
+        self._fused_step(st, x, x_next, t_all[i], dt, sigma)
+        # sampling_steps counts iterations whose x changed (977-980)
+        sampling_steps_dev += (st['changed'].max() > 0).to(torch.int64)
+        x, x_next = x_next, x
+      self._refresh_cache(st, x)
+      ops.subs_argmax(st['cache'], x, self.mask_index, out=x_next)
+      x = x_next.clone()
+      intermediate_tokens.append(x[:, :stride_length].cpu().numpy())
+      target = x[:, stride_length:]
+    intermediate_tokens.append(target.cpu().numpy())
+    sampling_steps = int(sampling_steps_dev.item())
+    if self.time_conditioning:
+      sampling_steps = (num_strides + 1) * (num_steps + 1)
+    intermediate_text_samples = []
+    sequence_lengths = ((
+      np.concatenate(intermediate_tokens, axis=1)[:, 1:]
+      == self.tokenizer.eos_token_id).cumsum(-1) == 0).sum(-1)
+    for i in range(2, len(intermediate_tokens) + 1):
+      intermediate_text_samples.append(self.tokenizer.batch_decode(
+        np.concatenate(intermediate_tokens[:i], axis=1)))
+    self.last_tokens = np.concatenate(intermediate_tokens, axis=1)
+    return sampling_steps, intermediate_text_samples, sequence_lengths
+
+  def restore_model_and_semi_ar_sample(self, stride_length, num_strides,
+                                       dt=0.001):
+    """diffusion.py:999-1024."""
+    self._ema_swap_in()
+    self.backbone.eval()
+    self.noise.eval()
+    out = self.sample_subs_guidance(
+      n_samples=self.config.loader.eval_batch_size,
+      stride_length=stride_length, num_strides=num_strides, dt=dt)
+    self._ema_swap_out()
+    self.backbone.train()
+    self.noise.train()
+    return out
+
+  # --------------------------------------------------------------- NELBO eval
+  def _sample_t(self, n, device):  # diffusion.py:800-808
+    _eps_t = torch.rand(n, device=device)
+    if self.antithetic_sampling:
+      offset = torch.arange(n, device=device) / n
+      _eps_t = (_eps_t / n + offset) % 1
+    return (1 - self.sampling_eps) * _eps_t + self.sampling_eps
+
+  def _forward_pass_diffusion(self, x0, *, t=None, u=None, attention_mask=None):
+    """diffusion.py:847-894 (subs, T = 0): q_xt -> backbone -> fused
+    SUBS + gather + dsigma/expm1(sigma) weight (kernel c2); the (B, L, V)
+    log-probs are never materialised."""
+    if t is None:
+      t = self._sample_t(x0.shape[0], x0.device)
+    sigma, dsigma = self.noise(t)
+    move_chance = 1 - torch.exp(-sigma[:, None])
+    xt = self.q_xt(x0, move_chance, u=u)
+    logits = self._backbone_logits(xt, sigma[:, None])
+    weight = dsigma / torch.expm1(sigma)
+    return ops.subs_nll(logits, xt, x0, weight, self.mask_index,
+                        attn_mask=attention_mask)
+
+  def _loss(self, x0, attention_mask, *, t=None, u=None):
+    """diffusion.py:896-916 -> Loss(loss=token_nll, nlls, token_mask)."""
+    if x0.shape[1] != self.config.model.length:
+      raise NotImplementedError('sub-sampling of longer sequences '
+                                '(text8-crop) is out of scope')
+    if attention_mask is None:
+      attention_mask = torch.ones_like(x0, dtype=torch.float32)
+    nlls = self._forward_pass_diffusion(x0, t=t, u=u,
+                                        attention_mask=attention_mask)
+    sums = ops.nll_sums(nlls, attention_mask)
+    token_nll = (sums[0] / sums[1]).float()
+    return Loss(loss=token_nll, nlls=nlls, token_mask=attention_mask)
+
+  def _compute_loss(self, batch, prefix):  # diffusion.py:360-384
+    attention_mask = batch.get('attention_mask', None)
+    losses = self._loss(batch['input_ids'], attention_mask)
+    metrics = {'train': self.train_metrics, 'val': self.valid_metrics,
+               'test': self.test_metrics}.get(prefix)
+    if metrics is None:
+      raise ValueError(f'Invalid prefix: {prefix}')
+    metrics.update(losses.nlls, losses.token_mask)
+    return losses.loss
+
+  def on_validation_epoch_start(self):  # diffusion.py:399-410
+    self._ema_swap_in()
+    self.backbone.eval()
+    self.noise.eval()
+    self.valid_metrics.reset()
+
+  @torch.no_grad()
+  def validation_step(self, batch, batch_idx):  # diffusion.py:412-413
+    return self._compute_loss(batch, prefix='val')
+
+  def on_validation_epoch_end(self):
+    self._ema_swap_out()
+    return self.valid_metrics.compute(sync_dist=True)

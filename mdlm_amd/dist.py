@@ -1,0 +1,82 @@
+"""One process per GPU; `torch.distributed` (backend "nccl" = RCCL over xGMI on
+ROCm, "gloo" for CPU tests).  The hot path shards by sample / eval sequence
+(SURVEY.md section 8(e)): nothing inside a sample crosses GPUs.  The only
+collective on the data path is ONE all-reduce of the fp64 pair
+[sum(nll * mask), sum(mask)] at the end of an eval epoch (the reference gets it
+from torchmetrics `sync_dist=True`, diffusion.py:380-383, 117-125)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+  return (int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)),
+          int(os.environ.get('WORLD_SIZE', 1)))
+
+
+def init(backend=None):
+  """Initialise the default process group from the torchrun environment.
+  Returns (rank, local_rank, world_size).  No-op for world_size == 1."""
+  rank, local_rank, world = env_rank()
+  if world > 1 and not dist.is_initialized():
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    if backend is None:
+      backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+      torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+  return rank, local_rank, world
+
+
+def world_size():
+  return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank():
+  return dist.get_rank() if dist.is_initialized() else 0
+
+
+def barrier():
+  if dist.is_initialized():
+    dist.barrier()
+
+
+def shard_indices(n_items, rank_, world):
+  """DistributedSampler-style sharding without shuffle (reference
+  dataloader.py:679-694): item i goes to rank i % world; every rank gets the
+  same count, the tail being padded by wrapping around."""
+  per = (n_items + world - 1) // world
+  total = per * world
+  idx = list(range(n_items)) + list(range(total - n_items))
+  return idx[rank_:total:world]
+
+
+def rank_seed(seed, rank_):
+  """The reference seeds every rank identically (main.py:190), so DDP ranks
+  would emit identical samples; replicas here offset the seed per rank."""
+  return int(seed) + int(rank_)
+
+
+def all_reduce_sums(sums):
+  """SUM all-reduce of the (2,) fp64 metric vector, in place."""
+  if dist.is_initialized() and dist.get_world_size() > 1:
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+  return sums
+
+
+def max_over_ranks(value, device):
+  t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+  if dist.is_initialized() and dist.get_world_size() > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  return t.item()
+
+
+def gather_tokens(x):
+  """Optional all_gather of (B, L) int64 samples (8 KiB/sample)."""
+  if not dist.is_initialized() or dist.get_world_size() == 1:
+    return x
+  out = [torch.empty_like(x) for _ in range(dist.get_world_size())]
+  dist.all_gather(out, x)
+  return torch.cat(out, 0)

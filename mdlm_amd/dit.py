@@ -111,6 +111,7 @@ class DIT(nn.Module):
     self.output_layer = DDitFinalLayer(self.hidden, vocab_size, self.cond_dim)
     self.scale_by_sigma = _cfg(config, 'scale_by_sigma')
     self._prep = None   # device-side kernel operands (bf16 weights, tables)
+    self.profile_events = None
     self._ws = None     # activation workspace
 
   # ------------------------------------------------------------ preparation
@@ -259,9 +260,17 @@ class DIT(nn.Module):
     ops.ln_modulate(x, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod,
                     ld2, n_rows_dev)
     assert logits_out.shape[-1] == self.vocab_size
+    ev = getattr(self, 'profile_events', None)
+    if ev is not None:  # bench.py: live HIP-event timing of the dominant kernel
+      e0 = torch.cuda.Event(enable_timing=True)
+      e1 = torch.cuda.Event(enable_timing=True)
+      e0.record()
     ops.gemm_bf16(h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
                   rows_per_mod=L, m_rows_dev=n_rows_dev, out_sample_map=active,
                   ldc=logits_out.stride(-2), M=M)
+    if ev is not None:
+      e1.record()
+      ev.append((e0, e1, n_rows_dev.clone() if n_rows_dev is not None else M))
     return logits_out
 
   def forward(self, indices, sigma, out=None, out_dtype=torch.bfloat16):

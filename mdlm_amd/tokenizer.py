@@ -1,0 +1,35 @@
+"""Tokenizer handling for the offline hot path.  The reference uses the GPT-2
+BPE tokenizer from the HF hub (dataloader.py:488-522), which is unavailable
+offline; only its *contract* matters to the sampler: vocab_size 50257,
+bos = eos = 50256 and no mask token (so mask_index = vocab_size,
+diffusion.py:85-90)."""
+import os
+
+
+class SyntheticTokenizer:
+  """GPT-2-shaped stand-in: ids decode to `<id>` strings."""
+
+  def __init__(self, vocab_size=50257, bos_token_id=50256, eos_token_id=50256,
+               mask_token_id=None):
+    self.vocab_size = vocab_size
+    self.bos_token_id = bos_token_id
+    self.eos_token_id = eos_token_id
+    self.pad_token_id = eos_token_id
+    self.mask_token_id = mask_token_id
+    self.mask_token = None if mask_token_id is None else '[MASK]'
+
+  def decode(self, ids):
+    return ' '.join(f'<{int(i)}>' for i in ids)
+
+  def batch_decode(self, batch):
+    return [self.decode(row) for row in batch]
+
+
+def get_tokenizer(config):
+  """A local tokenizer directory is loaded with transformers; anything else
+  (hub names cannot be fetched offline) yields the synthetic stand-in."""
+  path = config.data.tokenizer_name_or_path
+  if isinstance(path, str) and os.path.isdir(path):
+    import transformers
+    return transformers.AutoTokenizer.from_pretrained(path)
+  return SyntheticTokenizer(vocab_size=int(config.data.get('vocab_size', 50257)))
