@@ -177,6 +177,11 @@ int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
                    const int32_t* m_rows_dev, const int32_t* out_sample_map,
                    void* stream);
 
+/* Test hook, no reference counterpart: force_small != 0 makes mdlm_gemm_bf16
+ * always use its 128x128 tile (default: 256x256 when M % 256 == 0 and
+ * N >= 256) so that both configurations can be parity-tested on any shape. */
+int mdlm_gemm_set_tile(int force_small);
+
 /* Bidirectional attention, dit.py:265-275 (flash_attn_varlen_qkvpacked_func,
  * equal lengths, no dropout, softmax scale 1/sqrt(64)): q,k (n_seq,H,L,64)
  * bf16, vt (n_seq,H,64,L) bf16 -> out (n_seq*L, H*64) bf16.  L % 128 == 0. */

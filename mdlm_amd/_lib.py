@@ -37,6 +37,7 @@ SIGNATURES = {
                      _i32, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp,
                      _vp],
   'mdlm_attn_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
+  'mdlm_gemm_set_tile': [_i32],
   'mdlm_compact_active': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
 }
 

@@ -272,3 +272,8 @@ def attn_fwd(q, k, vt, out, n_seq, H, L, n_seq_dev=None):
   call('mdlm_attn_fwd', q.data_ptr(), k.data_ptr(), vt.data_ptr(),
        out.data_ptr(), int(n_seq), int(H), int(L), _p(n_seq_dev), _stream())
   return out
+
+
+def gemm_set_tile(force_small):
+  """Test hook: force the 128x128 GEMM tile (see mdlm_gemm_set_tile)."""
+  call('mdlm_gemm_set_tile', int(bool(force_small)))

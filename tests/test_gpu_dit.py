@@ -12,11 +12,14 @@ import mdlm_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module')
-def ops():
+@pytest.fixture(scope='module', params=['tile256', 'tile128'])
+def ops(request):
+  """Every test runs with both GEMM tile configurations."""
   assert torch.cuda.is_available()
   from mdlm_amd import ops as _ops
-  return _ops
+  _ops.gemm_set_tile(request.param == 'tile128')
+  yield _ops
+  _ops.gemm_set_tile(False)
 
 
 def _bf(t):
@@ -81,7 +84,8 @@ def _gemm_ref(A, W, bias=None):
 
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 384, 128), (128, 1000, 192),
-                                   (384, 2304, 768), (128, 777, 768)])
+                                   (384, 2304, 768), (128, 777, 768), (512, 1000, 256),
+                                   (1024, 768, 3072)])
 def test_gemm_store(ops, M, N, K):
   from mdlm_amd._lib import EPI_STORE
   torch.manual_seed(2)
@@ -118,7 +122,7 @@ def test_gemm_identity_asymmetric(ops):
 def test_gemm_live_rows_and_scatter(ops):
   from mdlm_amd._lib import EPI_STORE
   torch.manual_seed(3)
-  L, B, N, K = 128, 4, 320, 64
+  L, B, N, K = 256, 4, 320, 64
   A = torch.randn(B * L, K); W = torch.randn(N, K)
   ref = _gemm_ref(A, W)
   C = torch.full((B * L, N), -5.0, device='cuda')
@@ -135,7 +139,7 @@ def test_gemm_live_rows_and_scatter(ops):
 def test_gemm_gelu_and_gate_residual(ops):
   from mdlm_amd._lib import EPI_BIAS_GELU, EPI_GATE_RESIDUAL
   torch.manual_seed(4)
-  B, L, N, K = 2, 128, 256, 128
+  B, L, N, K = 2, 256, 512, 128
   M = B * L
   A = torch.randn(M, K); W = torch.randn(N, K) * 0.2; bias = torch.randn(N)
   y = _gemm_ref(A, W, bias)
@@ -173,7 +177,7 @@ def _qkv_ref(h, Wqkv, B, L, H):
 def test_gemm_qkv_rotary_layout(ops):
   from mdlm_amd._lib import EPI_QKV_ROTARY
   torch.manual_seed(5)
-  B, L, H = 2, 128, 2
+  B, L, H = 2, 256, 2
   D = H * 64
   M = B * L
   h = torch.randn(M, D); Wqkv = torch.randn(3 * D, D) * 0.1
@@ -228,7 +232,7 @@ def _make_model(hidden, heads, blocks, cond, V, seed):
   return m.cuda(), p
 
 
-@pytest.mark.parametrize('shape', [(128, 2, 2, 64, 300, 128), (768, 12, 2, 128, 1000, 256)])
+@pytest.mark.parametrize('shape', [(128, 2, 2, 64, 300, 128), (768, 12, 2, 128, 1000, 256), (128, 2, 1, 64, 700, 512)])
 def test_dit_forward_vs_oracle(ops, shape):
   hidden, heads, blocks, cond, V, L = shape
   model, p = _make_model(hidden, heads, blocks, cond, V, seed=3)
@@ -254,7 +258,7 @@ def test_dit_forward_vs_oracle(ops, shape):
 
 def test_dit_active_compaction_is_batch_invariant(ops):
   """Per-sample evaluation must be bit-identical to the full-batch one."""
-  hidden, heads, blocks, cond, V, L = 128, 2, 2, 64, 300, 128
+  hidden, heads, blocks, cond, V, L = 128, 2, 2, 64, 300, 256
   model, _ = _make_model(hidden, heads, blocks, cond, V, seed=4)
   torch.manual_seed(8)
   B = 5
