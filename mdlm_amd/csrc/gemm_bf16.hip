@@ -7,16 +7,24 @@
 //   256x256x64, 512 threads = 8 waves (2 M x 4 N), wave tile 128x64  (M % 256 == 0)
 //   128x128x64, 256 threads = 4 waves (2 M x 2 N), wave tile  64x64  (M % 128 == 0)
 // MFMA 16x16x32 bf16, fp32 accumulators.  A and W tiles are staged global->LDS
-// with 16-byte global_load_lds (LDS-DMA), double-buffered (2 x 64 KiB for the
-// 256^2 tile: half the L2->LDS bytes per flop of the 128^2 tile, which is
-// what bounds these K=768 GEMMs).  The LDS image is lane-linear with the
-// 16-byte chunk index XOR-swizzled by (row & 7) on the SOURCE address and
-// un-swizzled on the ds_read_b128 fragment reads (conflict-free for the
-// 16x16x32 operand map).  Epilogues go through LDS (each wave its own 64x64
-// fp32 region) so that global stores are row-contiguous 8/16-byte vectors.
+// with 16-byte global_load_lds (LDS-DMA), double-buffered.  The LDS image is
+// lane-linear with the 16-byte chunk index XOR-swizzled by (row & 7) on the
+// SOURCE address and un-swizzled on the ds_read_b128 fragment reads
+// (conflict-free for the 16x16x32 operand map).
+//
+// Operand order: the MFMA is issued as D = W_frag x A_frag, i.e. it computes
+// 16x16 tiles of C^T: a lane then holds FOUR CONSECUTIVE OUTPUT COLUMNS of one
+// output row (D row = n, D col = m).  That makes the epilogue cheap: bias /
+// GELU / rotary are applied in registers, four values are packed and written
+// with ONE ds_write_b64 (bf16) or ds_write_b128 (fp32) into a swizzled
+// per-wave LDS tile, and read back as whole rows for 16-byte coalesced global
+// stores.  Only the V slice of the QKV GEMM keeps the natural order (a lane
+// then holds four consecutive ROWS = positions, which is what the transposed
+// v^T[b,h,d,l] store wants).
 // Block ids are remapped so that each XCD (private 4 MiB L2) walks groups of
 // M-tiles x all N-tiles: the A panels stay L2-resident while W streams.
 #include "common.h"
+#include <type_traits>
 
 namespace mdlm {
 
@@ -37,7 +45,8 @@ struct GemmArgs {
   const float* rot_cos; const float* rot_sin; int n_heads;
   const int32_t* m_rows_dev;
   int tiles_m, tiles_n;
-  int vec_ok;  // ldc / alignment allow vector stores
+  int vec_ok;  // ldc / alignment allow 16-byte row stores
+  int dbg;     // timing experiments only (bit 1: skip the epilogue)
 };
 
 #define GLDS16(gptr, lptr) \
@@ -45,26 +54,49 @@ struct GemmArgs {
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-  // nn.GELU(approximate='tanh'), dit.py:227
-  const float y = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  const float e = __expf(2.f * y);
-  const float th = 1.f - 2.f / (e + 1.f);
-  return 0.5f * x * (1.f + th);
+  // nn.GELU(approximate='tanh'), dit.py:227:
+  //   0.5 x (1 + tanh(y)) = x * sigmoid(2y),  y = sqrt(2/pi) (x + 0.044715 x^3)
+  // exp(-z) = exp2(-z log2 e); v_exp_f32 / v_rcp_f32 are 1-ulp hardware ops,
+  // far inside the bf16 output rounding.
+  const float z2 = -2.3022082f * x * (1.f + 0.044715f * x * x);  // -1.5957691*log2(e)
+  return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(z2));
 }
 
 __device__ __forceinline__ float bf16_round(float x) { return bf16_to_f32(f32_to_bf16(x)); }
 
-// Epilogue of one 64x64 wave sub-tile held as acc[4][4] (16x16 MFMA tiles):
-// grow0/gcol0 = its first global row / column; ep = this wave's 16 KiB LDS
-// staging region.  rows_per_mod % 64 == 0 whenever rows are decomposed into
-// (sample, position), so a 64-row tile never straddles two samples.
+// 16-byte row store of the epilogue.  dbg bits are timing experiments only:
+// 4 = drop the store, 8 = non-temporal, 16 = sc1 (write-through, not kept in L2).
+__device__ __forceinline__ void store16(void* p, uint4 v, int dbg) {
+  if (dbg & 4) return;
+  if (dbg & 8) {
+    __builtin_nontemporal_store(v.x, reinterpret_cast<unsigned*>(p));
+    __builtin_nontemporal_store(v.y, reinterpret_cast<unsigned*>(p) + 1);
+    __builtin_nontemporal_store(v.z, reinterpret_cast<unsigned*>(p) + 2);
+    __builtin_nontemporal_store(v.w, reinterpret_cast<unsigned*>(p) + 3);
+  } else if (dbg & 16) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 vv = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(vv) : "memory");
+  } else {
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+}
+
+
+// Epilogue of one 64x64 wave sub-tile.  SWAPPED accumulators (see header):
+// acc(m, n)[j] = C[grow0 + m*16 + fr][gcol0 + n*16 + fq*4 + j].
+// ep = this wave's 16 KiB LDS staging region.  rows_per_mod % 64 == 0 whenever
+// rows are decomposed into (sample, position), so a tile never straddles two
+// samples.
 template <int EPI, typename TC, int MT, int HALF>
-__device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], float* ep,
+__device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char* ep,
                                                int64_t grow0, int gcol0,
                                                const GemmArgs& g, int lane) {
   const int fq = lane >> 4, fr = lane & 15;
   if (gcol0 >= g.N) return;  // wave tile entirely past the N edge (wave-uniform)
 #define acc(m, n) accf[HALF * 4 + (m)][n]
+  constexpr bool BF16_OUT = sizeof(TC) == 2;
+
   if constexpr (EPI == MDLM_EPI_QKV_ROTARY) {
     const int cg = gcol0 >> 6;               // (three, head) column group
     const int three = cg / g.n_heads;
@@ -74,7 +106,8 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], float
     const int64_t pos0 = grow0 - b * L;
     bf16_t* const base = reinterpret_cast<bf16_t*>(g.C) + (int64_t)three * g.M * g.n_heads * 64;
     if (three == 2) {
-      // v^T[b,h,d,l]: a lane holds 4 consecutive l for one d -> 8-byte stores
+      // NATURAL accumulators here: acc(m, n)[j] = C[m*16 + fq*4 + j][n*16 + fr];
+      // v^T[b,h,d,l]: 4 consecutive l for one d -> 8-byte stores
       bf16_t* const vb = base + ((b * g.n_heads + h) * 64) * L + pos0;
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -87,54 +120,54 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], float
         }
       return;
     }
+    // q / k: rotary in registers.  d = n*16 + fq*4 + j pairs with d + 32
+    // (tiles n and n+2); Linear output is bf16 under autocast (dit.py:256,
+    // 365); the rotary kernel reads bf16, rotates in fp32, writes bf16
+    // (dit.py:112-115, 264).
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 4; ++m) {
+      const int row = m * 16 + fr;
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          ep[(m * 16 + fq * 4 + jj) * 64 + n * 16 + fr] = acc(m, n)[jj];
-    // (the wave reads back only its own region: no block barrier needed)
-    const int c = (lane & 7) * 4;
-    bf16_t* const qb = base + ((b * g.n_heads + h) * L + pos0) * 64 + c;
-    const float* const cosb = g.rot_cos + pos0 * 32 + c;
-    const float* const sinb = g.rot_sin + pos0 * 32 + c;
+      for (int n = 0; n < 2; ++n) {
+        const int d = n * 16 + fq * 4;
+        const float4 cs = *reinterpret_cast<const float4*>(g.rot_cos + (pos0 + row) * 32 + d);
+        const float4 sn = *reinterpret_cast<const float4*>(g.rot_sin + (pos0 + row) * 32 + d);
+        const float a0 = bf16_round(acc(m, n)[0]), a1 = bf16_round(acc(m, n)[1]);
+        const float a2 = bf16_round(acc(m, n)[2]), a3 = bf16_round(acc(m, n)[3]);
+        const float b0 = bf16_round(acc(m, n + 2)[0]), b1 = bf16_round(acc(m, n + 2)[1]);
+        const float b2 = bf16_round(acc(m, n + 2)[2]), b3 = bf16_round(acc(m, n + 2)[3]);
+        const uint2 lo = make_uint2(pack_bf16x2(a0 * cs.x - b0 * sn.x, a1 * cs.y - b1 * sn.y),
+                                    pack_bf16x2(a2 * cs.z - b2 * sn.z, a3 * cs.w - b3 * sn.w));
+        const uint2 hi = make_uint2(pack_bf16x2(a0 * sn.x + b0 * cs.x, a1 * sn.y + b1 * cs.y),
+                                    pack_bf16x2(a2 * sn.z + b2 * cs.z, a3 * sn.w + b3 * cs.w));
+        // bf16 tile [64][64], 16-B chunk index swizzled by (row & 7)
+        const int c_lo = n * 2 + (fq >> 1), c_hi = c_lo + 4;
+        *reinterpret_cast<uint2*>(ep + row * 128 + ((c_lo ^ (row & 7)) * 16) + (fq & 1) * 8) = lo;
+        *reinterpret_cast<uint2*>(ep + row * 128 + ((c_hi ^ (row & 7)) * 16) + (fq & 1) * 8) = hi;
+      }
+    }
+    bf16_t* const qb = base + ((b * g.n_heads + h) * L + pos0) * 64;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int row = it * 8 + (lane >> 3);
-      const float4 x1 = *reinterpret_cast<const float4*>(ep + row * 64 + c);
-      const float4 x2 = *reinterpret_cast<const float4*>(ep + row * 64 + c + 32);
-      const float4 cs = *reinterpret_cast<const float4*>(cosb + row * 32);
-      const float4 sn = *reinterpret_cast<const float4*>(sinb + row * 32);
-      // Linear output is bf16 under autocast (dit.py:256, 365); the rotary
-      // kernel reads bf16, rotates in fp32, writes bf16 (dit.py:112-115, 264)
-      const float a0 = bf16_round(x1.x), a1 = bf16_round(x1.y), a2 = bf16_round(x1.z), a3 = bf16_round(x1.w);
-      const float b0 = bf16_round(x2.x), b1 = bf16_round(x2.y), b2 = bf16_round(x2.z), b3 = bf16_round(x2.w);
-      bf16_t* dst = qb + row * 64;
-      *reinterpret_cast<uint2*>(dst) = make_uint2(
-        pack_bf16x2(a0 * cs.x - b0 * sn.x, a1 * cs.y - b1 * sn.y),
-        pack_bf16x2(a2 * cs.z - b2 * sn.z, a3 * cs.w - b3 * sn.w));
-      *reinterpret_cast<uint2*>(dst + 32) = make_uint2(
-        pack_bf16x2(a0 * sn.x + b0 * cs.x, a1 * sn.y + b1 * cs.y),
-        pack_bf16x2(a2 * sn.z + b2 * cs.z, a3 * sn.w + b3 * cs.w));
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((ch ^ (row & 7)) * 16));
+      store16(qb + row * 64 + ch * 8, v, g.dbg);
     }
+    return;
   } else {
+    // per-lane column constants: columns gcol0 + n*16 + fq*4 + (0..3)
+    float4 bias4[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          ep[(m * 16 + fq * 4 + jj) * 64 + n * 16 + fr] = acc(m, n)[jj];
-    const int c = (lane & 15) * 4;
-    const int gc = gcol0 + c;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.bias) {
-      if (gc + 3 < g.N) bias4 = *reinterpret_cast<const float4*>(g.bias + gc);
-      else {
-        if (gc < g.N) bias4.x = g.bias[gc];
-        if (gc + 1 < g.N) bias4.y = g.bias[gc + 1];
-        if (gc + 2 < g.N) bias4.z = g.bias[gc + 2];
+    for (int n = 0; n < 4; ++n) {
+      const int gc = gcol0 + n * 16 + fq * 4;
+      bias4[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g.bias) {
+        if (gc + 3 < g.N) bias4[n] = *reinterpret_cast<const float4*>(g.bias + gc);
+        else {
+          if (gc < g.N) bias4[n].x = g.bias[gc];
+          if (gc + 1 < g.N) bias4[n].y = g.bias[gc + 1];
+          if (gc + 2 < g.N) bias4[n].z = g.bias[gc + 2];
+        }
       }
     }
     // output row of tile row 0 (scatter of compacted samples, STORE only)
@@ -145,59 +178,93 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], float
         orow0 = (int64_t)g.out_sample_map[sidx] * g.rows_per_mod + (grow0 - sidx * g.rows_per_mod);
       }
     }
-    float4 gt = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* gate_row = nullptr;
     if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL) {
       // gate row is constant over the tile (rows_per_mod % 64 == 0)
       const int64_t mrow = g.n_mod == 1 ? 0 : (grow0 / g.rows_per_mod) % g.n_mod;
-      gt = *reinterpret_cast<const float4*>(g.gate + mrow * g.mod_ld + gc);
+      gate_row = g.gate + mrow * g.mod_ld;
     }
-    TC* const Cp = reinterpret_cast<TC*>(g.C) + orow0 * g.ldc + gc;
+    TC* const Cp = reinterpret_cast<TC*>(g.C) + orow0 * g.ldc + gcol0;
     const bool fast = g.vec_ok && (gcol0 + 63 < g.N);  // wave-uniform
     if (fast) {
+      if constexpr (BF16_OUT) {
+        // registers -> (bias, GELU) -> packed bf16 -> swizzled LDS tile [64][64]
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4);
-        float4 v = *reinterpret_cast<const float4*>(ep + row * 64 + c);
-        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-        if constexpr (EPI == MDLM_EPI_BIAS_GELU) {
-          v.x = gelu_tanh(v.x); v.y = gelu_tanh(v.y); v.z = gelu_tanh(v.z); v.w = gelu_tanh(v.w);
+        for (int m = 0; m < 4; ++m) {
+          const int row = m * 16 + fr;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            float v0 = acc(m, n)[0] + bias4[n].x, v1 = acc(m, n)[1] + bias4[n].y;
+            float v2 = acc(m, n)[2] + bias4[n].z, v3 = acc(m, n)[3] + bias4[n].w;
+            if constexpr (EPI == MDLM_EPI_BIAS_GELU) {
+              v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
+            }
+            const int c16 = n * 2 + (fq >> 1);
+            *reinterpret_cast<uint2*>(ep + row * 128 + ((c16 ^ (row & 7)) * 16) + (fq & 1) * 8) =
+              make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+          }
         }
-        if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL) {
-          // residual + gate * x (bias_dropout_add_scale, eval), dit.py:28-34
-          const float4 rs = *reinterpret_cast<const float4*>(g.residual + (grow0 + row) * g.ldc + gc);
-          v.x = rs.x + gt.x * v.x; v.y = rs.y + gt.y * v.y;
-          v.z = rs.z + gt.z * v.z; v.w = rs.w + gt.w * v.w;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + (lane >> 3), ch = lane & 7;
+          const uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((ch ^ (row & 7)) * 16));
+          store16(Cp + (int64_t)row * g.ldc + ch * 8, v, g.dbg);
         }
-        TC* dst = Cp + (int64_t)row * g.ldc;
-        if constexpr (sizeof(TC) == 4) {
-          *reinterpret_cast<float4*>(dst) = v;
-        } else {
-          *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+      } else {
+        // fp32 tile [64][64], 16-B chunk index swizzled by (row & 15)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int row = m * 16 + fr;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const int c16 = n * 4 + fq;
+            *reinterpret_cast<f32x4*>(ep + row * 256 + ((c16 ^ (row & 15)) * 16)) = acc(m, n);
+          }
+        }
+        const int ch = lane & 15;
+        const int gc = gcol0 + ch * 4;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), gt = b4;
+        if (g.bias) b4 = *reinterpret_cast<const float4*>(g.bias + gc);
+        if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL) gt = *reinterpret_cast<const float4*>(gate_row + gc);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int row = it * 4 + (lane >> 4);
+          float4 v = *reinterpret_cast<const float4*>(ep + row * 256 + ((ch ^ (row & 15)) * 16));
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL) {
+            // residual + gate * x (bias_dropout_add_scale, eval), dit.py:28-34
+            const float4 rs = *reinterpret_cast<const float4*>(g.residual + (grow0 + row) * g.ldc + gc);
+            v.x = rs.x + gt.x * v.x; v.y = rs.y + gt.y * v.y;
+            v.z = rs.z + gt.z * v.z; v.w = rs.w + gt.w * v.w;
+          }
+          store16(Cp + (int64_t)row * g.ldc + ch * 4, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), g.dbg);
         }
       }
     } else {
-      // N edge / unaligned ldc: element-wise masked stores
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4);
-        float4 v = *reinterpret_cast<const float4*>(ep + row * 64 + c);
-        float vv[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
-        TC* dst = Cp + (int64_t)row * g.ldc;
-        for (int e = 0; e < 4; ++e) {
-          if (gc + e < g.N) {
-            float o = vv[e];
-            if constexpr (EPI == MDLM_EPI_BIAS_GELU) o = gelu_tanh(o);
-            if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL) {
-              const float gte = e == 0 ? gt.x : e == 1 ? gt.y : e == 2 ? gt.z : gt.w;
-              o = g.residual[(grow0 + row) * g.ldc + gc + e] + gte * o;
+      // N edge / unaligned ldc: element-wise masked stores straight from registers
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int row = m * 16 + fr;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const float bb[4] = {bias4[n].x, bias4[n].y, bias4[n].z, bias4[n].w};
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int cc = n * 16 + fq * 4 + jj;
+            if (gcol0 + cc < g.N) {
+              float o = acc(m, n)[jj] + bb[jj];
+              if constexpr (EPI == MDLM_EPI_BIAS_GELU) o = gelu_tanh(o);
+              if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL)
+                o = g.residual[(grow0 + row) * g.ldc + gcol0 + cc] + gate_row[gcol0 + cc] * o;
+              elem<TC>::store(Cp + (int64_t)row * g.ldc + cc, o);
             }
-            elem<TC>::store(dst + e, o);
           }
         }
       }
     }
   }
-}
 #undef acc
+}
 
 // WM x WN waves; each wave MT x 4 MFMA tiles (MT*16 rows x 64 columns).
 template <int EPI, typename TC, int WM, int WN, int MT>
@@ -223,6 +290,17 @@ void gemm_bf16_kernel(GemmArgs g) {
   const int64_t m0 = (int64_t)tm * TBM;
   if (g.m_rows_dev && m0 >= (int64_t)*g.m_rows_dev) return;
   const int n0 = tn * TBN;
+
+  // Phase stagger (timing experiment, dbg >> 8 = delay in ~1 us units): all
+  // tiles take the same time, so co-scheduled workgroups otherwise run their
+  // store-heavy epilogues in lockstep; delaying half of the first resident set
+  // once puts half of the chip's epilogues under the other half's main loops.
+  if (g.dbg >> 8) {
+    constexpr int RES = (NW == 8) ? 256 : 512;  // first resident set
+    const bool late = (NW == 8) ? ((bid >> 3) & 1) : (bid >= 256);
+    if (bid < RES && late)
+      for (int i = 0; i < (g.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(32);
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -273,34 +351,52 @@ void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // natural operand order only for the V slice of the QKV GEMM (wave-uniform)
+  bool natural = false;
+  if constexpr (EPI == MDLM_EPI_QKV_ROTARY)
+    natural = ((n0 + wc * 64) >> 6) / g.n_heads == 2;
+
   const int KT = g.K / BK;
-  stage(0, 0);
-  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) before the barrier
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) stage(cur ^ 1, (kt + 1) * BK);
-    const char* At = ldsA + cur * A_BYTES + a_base;
-    const char* Bt = ldsB + cur * B_BYTES + b_base;
+  auto mainloop = [&](auto nat) {
+    constexpr bool NAT = decltype(nat)::value;
+    stage(0, 0);
+    __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) before the barrier
+    for (int kt = 0; kt < KT; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < KT) stage(cur ^ 1, (kt + 1) * BK);
+      const char* At = ldsA + cur * A_BYTES + a_base;
+      const char* Bt = ldsB + cur * B_BYTES + b_base;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[MT], bfr[4];
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-        bfr[n] = *reinterpret_cast<const bf16x8*>(Bt + n * 2048 + foff[ks]);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-        af[m] = *reinterpret_cast<const bf16x8*>(At + m * 2048 + foff[ks]);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[MT], bfr[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+          bfr[n] = *reinterpret_cast<const bf16x8*>(Bt + n * 2048 + foff[ks]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          af[m] = *reinterpret_cast<const bf16x8*>(At + m * 2048 + foff[ks]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            if constexpr (NAT)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+            else
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[n], af[m], acc[m][n], 0, 0, 0);
+          }
+      }
+      __syncthreads();
     }
-    __syncthreads();
+  };
+  if constexpr (EPI == MDLM_EPI_QKV_ROTARY) {
+    if (natural) mainloop(std::true_type{}); else mainloop(std::false_type{});
+  } else {
+    mainloop(std::false_type{});
   }
 
   // ---- epilogue: MT/4 passes of a 64x64 sub-tile through this wave's LDS ----
-  float* ep = reinterpret_cast<float*>(smem) + wid * 4096;
+  if (g.dbg & 2) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(g.C)[0] = 1.f; return; }
+  char* ep = smem + wid * 16384;
   const int gcol0 = n0 + wc * 64;
   const int64_t growW = m0 + wr * (MT * 16);
   epilogue_64x64<EPI, TC, MT, 0>(acc, ep, growW, gcol0, g, lane);
@@ -332,6 +428,7 @@ static int launch_cfg(GemmArgs g, hipStream_t s) {
 }
 
 static int g_force_small_tile = 0;  // test hook (mdlm_gemm_set_tile)
+static int g_dbg = 0;
 
 template <int EPI, typename TC>
 static int launch_gemm(const GemmArgs& g, hipStream_t s) {
@@ -345,7 +442,8 @@ static int launch_gemm(const GemmArgs& g, hipStream_t s) {
 using namespace mdlm;
 
 extern "C" int mdlm_gemm_set_tile(int force_small) {
-  g_force_small_tile = force_small;
+  g_force_small_tile = force_small & 1;
+  g_dbg = force_small & ~1;
   return 0;
 }
 
@@ -364,6 +462,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
   MDLM_CHECK_ARG(lda >= K && lda % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
                  "gemm_bf16: A/W must be 16-byte aligned with lda %% 8 == 0");
   MDLM_CHECK_ARG(M * (N > K ? N : K) < (1ll << 40), "gemm_bf16: too large");
+  MDLM_CHECK_ARG(!bias || ((uintptr_t)bias & 15) == 0, "gemm_bf16: bias must be 16-byte aligned");
   if (M == 0) return 0;
   GemmArgs g;
   g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.bias = bias;
@@ -371,9 +470,11 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
   g.rows_per_mod = rows_per_mod > 0 ? rows_per_mod : 1; g.n_mod = n_mod > 0 ? n_mod : 1;
   g.mod_ld = mod_ld; g.out_sample_map = out_sample_map;
   g.rot_cos = rot_cos; g.rot_sin = rot_sin; g.n_heads = n_heads; g.m_rows_dev = m_rows_dev;
-  g.tiles_m = 0; g.tiles_n = 0;
+  g.tiles_m = 0; g.tiles_n = 0; g.dbg = g_dbg;
   hipStream_t s = (hipStream_t)stream;
-  g.vec_ok = (((uintptr_t)C & 15) == 0) && (ldc % 4 == 0) ? 1 : 0;
+  // 16-byte row stores: 8 bf16 or 4 fp32 per lane
+  const int64_t per16 = dtype_c == MDLM_F32 ? 4 : 8;
+  g.vec_ok = (((uintptr_t)C & 15) == 0) && (ldc % per16 == 0) ? 1 : 0;
   switch (epilogue) {
     case MDLM_EPI_STORE:
       MDLM_CHECK_ARG(ldc >= N, "gemm_bf16: ldc < N");
@@ -396,7 +497,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
                      "gemm_bf16: QKV_ROTARY needs head_dim 64 (N == 3*H*64) and rotary tables");
       MDLM_CHECK_ARG(rows_per_mod > 0 && rows_per_mod % 64 == 0 && M % rows_per_mod == 0,
                      "gemm_bf16: QKV_ROTARY needs M %% L == 0 and L %% 64 == 0");
-      MDLM_CHECK_ARG(dtype_c == MDLM_BF16, "gemm_bf16: QKV_ROTARY writes bf16");
+      MDLM_CHECK_ARG(dtype_c == MDLM_BF16 && ((uintptr_t)C & 15) == 0, "gemm_bf16: QKV_ROTARY writes 16-byte aligned bf16");
       return launch_gemm<MDLM_EPI_QKV_ROTARY, bf16_t>(g, s);
     default:
       MDLM_CHECK_ARG(false, "gemm_bf16: unknown epilogue %d", epilogue);

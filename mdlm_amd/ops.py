@@ -276,4 +276,4 @@ def attn_fwd(q, k, vt, out, n_seq, H, L, n_seq_dev=None):
 
 def gemm_set_tile(force_small):
   """Test hook: force the 128x128 GEMM tile (see mdlm_gemm_set_tile)."""
-  call('mdlm_gemm_set_tile', int(bool(force_small)))
+  call('mdlm_gemm_set_tile', int(force_small))
