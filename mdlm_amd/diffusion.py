@@ -293,7 +293,9 @@ class Diffusion(_Base):
     if num_steps is None:
       num_steps = self.config.sampling.steps
     dev = self.device
-    timesteps = torch.linspace(1, eps, num_steps + 1, device=dev)
+    # computed on the host so that the fp32 values are those of the CPU
+    # reference path bit for bit (diffusion.py:669-670)
+    timesteps = torch.linspace(1, eps, num_steps + 1).to(dev)
     dt = (1 - eps) / num_steps
     if not self.config.sampling.get('fused', True):
       return self._sample_reference_loop(B, Lq, num_steps, timesteps, dt)
@@ -362,9 +364,12 @@ class Diffusion(_Base):
     intermediate_tokens = []
     target = None
     # t = (1 - i * dt) * ones  (diffusion.py:976), i = 0..num_steps (t = 0 last)
-    steps = torch.arange(num_steps + 1, device=dev, dtype=torch.float32)
-    t_all = ((1 - steps * dt)[:, None] * torch.ones(
-      n_samples, dtype=self.dtype, device=dev)[None]).contiguous()
+    # the Python double (1 - i * dt) rounded once to fp32, as the reference's
+    # scalar * fp32-tensor product does
+    t_host = torch.tensor([1 - i * dt for i in range(num_steps + 1)],
+                          dtype=torch.float64).to(self.dtype)
+    t_all = (t_host[:, None] * torch.ones(n_samples, dtype=self.dtype)[None]
+             ).contiguous().to(dev)
     sampling_steps_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     for _ in range(num_strides + 1):
       x, x_next = st['xa'], st['xb']
