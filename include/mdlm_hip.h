@@ -145,11 +145,13 @@ int mdlm_linear_f32(const float* in, const float* W, const float* bias,
  * dit.py:126-134 + 74-78: out = LN(x)*w*(1+scale)+shift -> bf16.
  * shift/scale: n_mod rows of D fp32, mod_ld elements apart; row r uses
  * modulation row (r / rows_per_mod) % n_mod (n_mod == 1: batch-invariant
- * conditioning, as with time_conditioning=False). */
+ * conditioning, as with time_conditioning=False).  row_gather (optional):
+ * output row r is computed from input row row_gather[r] (row compaction). */
 int mdlm_ln_modulate(const float* x, const float* ln_w, const float* shift,
                      const float* scale, void* out_bf16, int64_t rows, int D,
                      int64_t rows_per_mod, int n_mod, int64_t mod_ld,
-                     const int32_t* n_rows_dev, void* stream);
+                     const int32_t* row_gather, const int32_t* n_rows_dev,
+                     void* stream);
 
 /* nn.Linear on bf16 MFMA, dit.py:220-228, 256, 277, 306/320:
  * C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  A bf16 (lda), W bf16 contiguous.
@@ -157,7 +159,10 @@ int mdlm_ln_modulate(const float* x, const float* ln_w, const float* shift,
  *   STORE          : C (ldc, dtype_c) = acc + bias.  out_sample_map (optional):
  *                    output row r is written to row out_sample_map[r / L] * L
  *                    + r % L with L = rows_per_mod (scatter of compacted samples
- *                    back into a per-sample logits cache).
+ *                    back into a per-sample logits cache).  out_row_map
+ *                    (optional, exclusive with out_sample_map): output row r
+ *                    is written to row out_row_map[r], or dropped if < 0
+ *                    (logits of the masked rows only, see mdlm_masked_row_map).
  *   BIAS_GELU      : C bf16 = gelu_tanh(acc + bias)            (dit.py:225-228)
  *   GATE_RESIDUAL  : C fp32 = residual + gate[(row/rows_per_mod) % n_mod] *
  *                    (acc + bias); gate rows mod_ld elements apart
@@ -175,7 +180,7 @@ int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
                    int64_t rows_per_mod, int n_mod, int64_t mod_ld,
                    const float* rot_cos, const float* rot_sin, int n_heads,
                    const int32_t* m_rows_dev, const int32_t* out_sample_map,
-                   void* stream);
+                   const int32_t* out_row_map, void* stream);
 
 /* Test hook, no reference counterpart: force_small != 0 makes mdlm_gemm_bf16
  * always use its 128x128 tile (default: 256x256 when M % 256 == 0 and
@@ -200,6 +205,18 @@ int mdlm_attn_fwd(const void* q, const void* k, const void* vt, void* out,
 int mdlm_compact_active(const int32_t* changed, int32_t* active,
                         int32_t* n_active, int32_t* n_rows, int B, int L,
                         int all_or_nothing, int64_t* nfe_accum, void* stream);
+
+/* Row lists of the MASKED rows of the active samples: only those rows need
+ * logits (an unmasked token is carried over, diffusion.py:609-610, and SUBS
+ * ignores its logits, 274-276).  gather[k] = compacted workspace row
+ * (i*L + pos for active[i]), scatter[k] = logits-cache row (active[i]*L + pos),
+ * in ascending order, padded with (0, -1) to a multiple of `pad`;
+ * *n_out = padded count.  No reference counterpart (the reference projects
+ * every row, dit.py:320). */
+int mdlm_masked_row_map(const int64_t* x, const int32_t* active,
+                        const int32_t* n_active, int L, int mask_index, int pad,
+                        int32_t* gather, int32_t* scatter, int32_t* n_out,
+                        void* stream);
 
 #ifdef __cplusplus
 }

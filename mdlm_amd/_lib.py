@@ -32,10 +32,12 @@ SIGNATURES = {
   'mdlm_embed_rows': [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _vp],
   'mdlm_timestep_embedding': [_vp, _vp, _i32, _i32, _vp],
   'mdlm_linear_f32': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
-  'mdlm_ln_modulate': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i64, _vp, _vp],
+  'mdlm_ln_modulate': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i64, _vp, _vp,
+                       _vp],
+  'mdlm_masked_row_map': [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
   'mdlm_gemm_bf16': [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32,
                      _i32, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp,
-                     _vp],
+                     _vp, _vp],
   'mdlm_attn_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
   'mdlm_gemm_set_tile': [_i32],
   'mdlm_compact_active': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],

@@ -69,10 +69,12 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
     const float* __restrict__ x, const float* __restrict__ ln_w,
     const float* __restrict__ shift, const float* __restrict__ scale,
     bf16_t* __restrict__ out, int64_t rows, int D, int64_t rows_per_mod,
-    int n_mod, int64_t mod_ld, const int32_t* __restrict__ n_rows_dev) {
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int n_mod, int64_t mod_ld, const int32_t* __restrict__ row_gather,
+    const int32_t* __restrict__ n_rows_dev) {
+  const int64_t ro = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // output row
   const int64_t live = n_rows_dev ? (int64_t)*n_rows_dev : rows;
-  if (r >= rows || r >= live) return;
+  if (ro >= rows || ro >= live) return;
+  const int64_t r = row_gather ? (int64_t)row_gather[ro] : ro;       // source row
   const int lane = threadIdx.x & 63;
   const int nv = D / 4;
   const float4* xr = reinterpret_cast<const float4*>(x + r * D);
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
   const float4* w4 = reinterpret_cast<const float4*>(ln_w);
   const float4* sh4 = reinterpret_cast<const float4*>(shift + mrow * mod_ld);
   const float4* sc4 = reinterpret_cast<const float4*>(scale + mrow * mod_ld);
-  uint2* o = reinterpret_cast<uint2*>(out + r * D);
+  uint2* o = reinterpret_cast<uint2*>(out + ro * D);
 #pragma unroll
   for (int i = 0; i < LN_NV; ++i) {
     const int c = lane + i * 64;
@@ -157,13 +159,14 @@ extern "C" int mdlm_ln_modulate(const float* x, const float* ln_w,
                                 const float* shift, const float* scale,
                                 void* out_bf16, int64_t rows, int D,
                                 int64_t rows_per_mod, int n_mod, int64_t mod_ld,
+                                const int32_t* row_gather,
                                 const int32_t* n_rows_dev, void* stream) {
   MDLM_CHECK_ARG(x && ln_w && shift && scale && out_bf16, "ln_modulate: null pointer");
   MDLM_CHECK_ARG(rows >= 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_NV, "ln_modulate: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_NV);
   MDLM_CHECK_ARG(rows_per_mod > 0 && n_mod > 0 && mod_ld % 4 == 0 && (n_mod == 1 || mod_ld >= D), "ln_modulate: bad modulation shape");
   MDLM_CHECK_ARG((((uintptr_t)x | (uintptr_t)ln_w | (uintptr_t)shift | (uintptr_t)scale | (uintptr_t)out_bf16) & 15) == 0, "ln_modulate: buffers must be 16-byte aligned");
   if (rows == 0) return 0;
-  ln_modulate_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, ST(stream)>>>(x, ln_w, shift, scale, (bf16_t*)out_bf16, rows, D, rows_per_mod, n_mod, mod_ld, n_rows_dev);
+  ln_modulate_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, ST(stream)>>>(x, ln_w, shift, scale, (bf16_t*)out_bf16, rows, D, rows_per_mod, n_mod, mod_ld, row_gather, n_rows_dev);
   MDLM_LAUNCH_CHECK();
   return 0;
 }

@@ -42,6 +42,7 @@ struct GemmArgs {
   const float* gate; const float* residual;
   int64_t rows_per_mod; int n_mod; int64_t mod_ld;
   const int32_t* out_sample_map;
+  const int32_t* out_row_map;
   const float* rot_cos; const float* rot_sin; int n_heads;
   const int32_t* m_rows_dev;
   int tiles_m, tiles_n;
@@ -184,7 +185,14 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
       const int64_t mrow = g.n_mod == 1 ? 0 : (grow0 / g.rows_per_mod) % g.n_mod;
       gate_row = g.gate + mrow * g.mod_ld;
     }
-    TC* const Cp = reinterpret_cast<TC*>(g.C) + orow0 * g.ldc + gcol0;
+    TC* const Cp0 = reinterpret_cast<TC*>(g.C) + gcol0;
+    // destination row of tile row `row` (per-row scatter list: STORE only; -1 = skip)
+    auto dst_row = [&](int row) -> int64_t {
+      if constexpr (EPI == MDLM_EPI_STORE) {
+        if (g.out_row_map) return (int64_t)g.out_row_map[grow0 + row];
+      }
+      return orow0 + row;
+    };
     const bool fast = g.vec_ok && (gcol0 + 63 < g.N);  // wave-uniform
     if (fast) {
       if constexpr (BF16_OUT) {
@@ -208,7 +216,8 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
         for (int it = 0; it < 8; ++it) {
           const int row = it * 8 + (lane >> 3), ch = lane & 7;
           const uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((ch ^ (row & 7)) * 16));
-          store16(Cp + (int64_t)row * g.ldc + ch * 8, v, g.dbg);
+          const int64_t dr = dst_row(row);
+          if (dr >= 0) store16(Cp0 + dr * g.ldc + ch * 8, v, g.dbg);
         }
       } else {
         // fp32 tile [64][64], 16-B chunk index swizzled by (row & 15)
@@ -237,7 +246,8 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
             v.x = rs.x + gt.x * v.x; v.y = rs.y + gt.y * v.y;
             v.z = rs.z + gt.z * v.z; v.w = rs.w + gt.w * v.w;
           }
-          store16(Cp + (int64_t)row * g.ldc + ch * 4, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), g.dbg);
+          const int64_t dr = dst_row(row);
+          if (dr >= 0) store16(Cp0 + dr * g.ldc + ch * 4, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), g.dbg);
         }
       }
     } else {
@@ -245,6 +255,8 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int row = m * 16 + fr;
+        const int64_t dr = dst_row(row);
+        if (dr < 0) continue;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           const float bb[4] = {bias4[n].x, bias4[n].y, bias4[n].z, bias4[n].w};
@@ -256,7 +268,7 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
               if constexpr (EPI == MDLM_EPI_BIAS_GELU) o = gelu_tanh(o);
               if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL)
                 o = g.residual[(grow0 + row) * g.ldc + gcol0 + cc] + gate_row[gcol0 + cc] * o;
-              elem<TC>::store(Cp + (int64_t)row * g.ldc + cc, o);
+              elem<TC>::store(Cp0 + dr * g.ldc + cc, o);
             }
           }
         }
@@ -298,7 +310,11 @@ void gemm_bf16_kernel(GemmArgs g) {
   if (g.dbg >> 8) {
     constexpr int RES = (NW == 8) ? 256 : 512;  // first resident set
     const bool late = (NW == 8) ? ((bid >> 3) & 1) : (bid >= 256);
-    if (bid < RES && late)
+    if (g.dbg & 32) {  // pseudo-random phase for every workgroup of the first set
+      const int n = (int)(((unsigned)bid * 2654435761u) >> 16) % (g.dbg >> 8);
+      if (bid < RES)
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+    } else if (bid < RES && late)
       for (int i = 0; i < (g.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(32);
   }
 
@@ -454,7 +470,8 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
                               int64_t rows_per_mod, int n_mod, int64_t mod_ld,
                               const float* rot_cos, const float* rot_sin,
                               int n_heads, const int32_t* m_rows_dev,
-                              const int32_t* out_sample_map, void* stream) {
+                              const int32_t* out_sample_map,
+                              const int32_t* out_row_map, void* stream) {
   MDLM_CHECK_ARG(A && W && C, "gemm_bf16: null pointer");
   MDLM_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_bf16: bad shape");
   MDLM_CHECK_ARG(M % 128 == 0, "gemm_bf16: M=%lld must be a multiple of 128", (long long)M);
@@ -468,7 +485,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
   g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.bias = bias;
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.gate = gate; g.residual = residual;
   g.rows_per_mod = rows_per_mod > 0 ? rows_per_mod : 1; g.n_mod = n_mod > 0 ? n_mod : 1;
-  g.mod_ld = mod_ld; g.out_sample_map = out_sample_map;
+  g.mod_ld = mod_ld; g.out_sample_map = out_sample_map; g.out_row_map = out_row_map;
   g.rot_cos = rot_cos; g.rot_sin = rot_sin; g.n_heads = n_heads; g.m_rows_dev = m_rows_dev;
   g.tiles_m = 0; g.tiles_n = 0; g.dbg = g_dbg;
   hipStream_t s = (hipStream_t)stream;
@@ -480,6 +497,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
       MDLM_CHECK_ARG(ldc >= N, "gemm_bf16: ldc < N");
       MDLM_CHECK_ARG(dtype_c == MDLM_F32 || dtype_c == MDLM_BF16, "gemm_bf16: bad dtype_c");
       MDLM_CHECK_ARG(!out_sample_map || g.rows_per_mod % 64 == 0, "gemm_bf16: out_sample_map needs rows_per_mod %% 64 == 0");
+      MDLM_CHECK_ARG(!(out_sample_map && out_row_map), "gemm_bf16: out_sample_map and out_row_map are exclusive");
       if (dtype_c == MDLM_F32) return launch_gemm<MDLM_EPI_STORE, float>(g, s);
       return launch_gemm<MDLM_EPI_STORE, bf16_t>(g, s);
     case MDLM_EPI_BIAS_GELU:

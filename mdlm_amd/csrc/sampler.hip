@@ -461,6 +461,54 @@ __global__ void compact_active_kernel(const int32_t* __restrict__ changed,
   }
 }
 
+// Row lists for the masked rows of the active samples (one workgroup, ordered):
+// gather[k]  = compacted workspace row (i * L + pos, i = index into active[])
+// scatter[k] = logits-cache row (active[i] * L + pos)
+// padded with (0, -1) up to a multiple of `pad`; *n_out = padded count.
+__global__ __launch_bounds__(1024) void masked_row_map_kernel(
+    const int64_t* __restrict__ x, const int32_t* __restrict__ active,
+    const int32_t* __restrict__ n_active, int L, int mask, int pad,
+    int32_t* __restrict__ gather, int32_t* __restrict__ scatter,
+    int32_t* __restrict__ n_out) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int n_rows = *n_active * L;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < n_rows; r0 += 1024) {
+    const int r = r0 + threadIdx.x;
+    int dst = -1;
+    bool on = false;
+    if (r < n_rows) {
+      const int i = r / L, pos = r - i * L;
+      dst = active[i] * L + pos;
+      on = x[dst] == mask;
+    }
+    const unsigned long long m = __ballot(on);
+    if (lane == 0) wsum[w] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int k = 0; k < w; ++k) off += wsum[k];
+    if (on) {
+      const int k = off + __popcll(m & ((1ull << lane) - 1ull));
+      gather[k] = r;
+      scatter[k] = dst;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int k = 0; k < 16; ++k) t += wsum[k];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  const int n = base_s;
+  const int np = (n + pad - 1) / pad * pad;
+  for (int k = n + threadIdx.x; k < np; k += 1024) { gather[k] = 0; scatter[k] = -1; }
+  if (threadIdx.x == 0) *n_out = np;
+}
+
 static bool is16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace mdlm
@@ -640,6 +688,18 @@ extern "C" int mdlm_compact_active(const int32_t* changed, int32_t* active,
                                    int64_t* nfe_accum, void* stream) {
   MDLM_CHECK_ARG(changed && active && n_active && n_rows && B >= 0 && L > 0, "compact_active: bad args");
   compact_active_kernel<<<1, 64, 0, ST(stream)>>>(changed, active, n_active, n_rows, B, L, all_or_nothing, nfe_accum);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_masked_row_map(const int64_t* x, const int32_t* active,
+                                   const int32_t* n_active, int L,
+                                   int mask_index, int pad, int32_t* gather,
+                                   int32_t* scatter, int32_t* n_out,
+                                   void* stream) {
+  MDLM_CHECK_ARG(x && active && n_active && gather && scatter && n_out, "masked_row_map: null pointer");
+  MDLM_CHECK_ARG(L > 0 && pad > 0, "masked_row_map: bad shape");
+  masked_row_map_kernel<<<1, 1024, 0, ST(stream)>>>(x, active, n_active, L, mask_index, pad, gather, scatter, n_out);
   MDLM_LAUNCH_CHECK();
   return 0;
 }

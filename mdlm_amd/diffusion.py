@@ -244,6 +244,8 @@ class Diffusion(_Base):
       changed=torch.ones(B, **i32), active=torch.zeros(B, **i32),
       n_active=torch.zeros(1, **i32), n_rows=torch.zeros(1, **i32),
       nfe=torch.zeros(1, dtype=torch.int64, device=dev),
+      gather=torch.zeros(B * Lq + 256, **i32), scatter=torch.zeros(B * Lq + 256, **i32),
+      n_mrows=torch.zeros(1, **i32),
       zeros=torch.zeros(B, dtype=torch.float32, device=dev))
     self._state = st
     return st
@@ -260,9 +262,15 @@ class Diffusion(_Base):
       ops.compact_active(st['changed'], st['active'], st['n_active'],
                          st['n_rows'], Lq, all_or_nothing=aon,
                          nfe_accum=st['nfe'])
+      row_map = None
+      if self.config.sampling.get('masked_rows_only', True) and (B * Lq) % 256 == 0:
+        # only masked rows need logits: carry-over / SUBS ignore the others
+        ops.masked_row_map(x, st['active'], st['n_active'], Lq, self.mask_index,
+                           st['gather'], st['scatter'], st['n_mrows'])
+        row_map = (st['gather'], st['scatter'], st['n_mrows'])
       self.backbone.run(x, st['zeros'], st['cache'], sigma_is_zero=True,
                         active=st['active'], n_active_dev=st['n_active'],
-                        n_rows_dev=st['n_rows'], n_max=B)
+                        n_rows_dev=st['n_rows'], n_max=B, row_map=row_map)
       ops.subs_row_lse(st['cache'], x, self.mask_index, out=st['lse'],
                        sample_map=st['active'], L=Lq, n_rows_dev=st['n_rows'])
     else:

@@ -213,13 +213,15 @@ class DIT(nn.Module):
 
   # ------------------------------------------------------------------ forward
   def run(self, indices, sigma, logits_out, sigma_is_zero=False, active=None,
-          n_active_dev=None, n_rows_dev=None, n_max=None):
+          n_active_dev=None, n_rows_dev=None, n_max=None, row_map=None):
     """Run the backbone.  `indices` (B, L) int64.  `logits_out`: (B, L, V)
     bf16/fp32 view (padded leading dimension allowed).  If `active` (int32
     device list) is given, only the listed samples are evaluated (compacted
     into rows 0..n*L of the workspace) and their logits are scattered to
     logits_out[active[i]]; n_active_dev / n_rows_dev are device counters and
-    n_max the launch bound."""
+    n_max the launch bound.  `row_map = (gather, scatter, n_dev)` from
+    `ops.masked_row_map` restricts the final LayerNorm + vocabulary projection
+    to the masked rows (the only rows whose logits are ever read)."""
     B, L = indices.shape
     p = self._prepare(L)
     D, H = self.hidden, self.n_heads
@@ -257,20 +259,31 @@ class DIT(nn.Module):
                     gate=mod[:, 5 * D:6 * D], residual=x, rows_per_mod=L,
                     n_mod=n_mod, mod_ld=ld6, m_rows_dev=n_rows_dev, M=M)
     fm = mods[-1]
-    ops.ln_modulate(x, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod,
-                    ld2, n_rows_dev)
     assert logits_out.shape[-1] == self.vocab_size
     ev = getattr(self, 'profile_events', None)
+    if row_map is not None:
+      gather, scatter, live = row_map
+      ops.ln_modulate(x, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod,
+                      ld2, n_rows_dev=live, row_gather=gather, rows=M)
+    else:
+      live = n_rows_dev
+      ops.ln_modulate(x, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod,
+                      ld2, n_rows_dev)
     if ev is not None:  # bench.py: live HIP-event timing of the dominant kernel
       e0 = torch.cuda.Event(enable_timing=True)
       e1 = torch.cuda.Event(enable_timing=True)
       e0.record()
-    ops.gemm_bf16(h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
-                  rows_per_mod=L, m_rows_dev=n_rows_dev, out_sample_map=active,
-                  ldc=logits_out.stride(-2), M=M)
+    if row_map is not None:
+      ops.gemm_bf16(h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
+                    m_rows_dev=live, out_row_map=scatter,
+                    ldc=logits_out.stride(-2), M=M)
+    else:
+      ops.gemm_bf16(h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
+                    rows_per_mod=L, m_rows_dev=n_rows_dev, out_sample_map=active,
+                    ldc=logits_out.stride(-2), M=M)
     if ev is not None:
       e1.record()
-      ev.append((e0, e1, n_rows_dev.clone() if n_rows_dev is not None else M))
+      ev.append((e0, e1, live.clone() if live is not None else M))
     return logits_out
 
   def forward(self, indices, sigma, out=None, out_dtype=torch.bfloat16):

@@ -237,20 +237,22 @@ def linear_f32(x, W, bias, act_in=0, act_out=0):
 
 
 def ln_modulate(x, ln_w, shift, scale, out, rows_per_mod, n_mod=1, mod_ld=0,
-                n_rows_dev=None):
+                n_rows_dev=None, row_gather=None, rows=None):
   """shift/scale: tensors (views allowed) whose row m starts m*mod_ld elements
   after data_ptr()."""
-  rows, D = x.shape
+  D = x.shape[1]
+  if rows is None:
+    rows = x.shape[0]
   call('mdlm_ln_modulate', x.data_ptr(), ln_w.data_ptr(), shift.data_ptr(),
-       scale.data_ptr(), out.data_ptr(), rows, D, int(rows_per_mod), int(n_mod),
-       int(mod_ld), _p(n_rows_dev), _stream())
+       scale.data_ptr(), out.data_ptr(), int(rows), D, int(rows_per_mod),
+       int(n_mod), int(mod_ld), _p(row_gather), _p(n_rows_dev), _stream())
   return out
 
 
 def gemm_bf16(A, W, C, epilogue=_lib.EPI_STORE, bias=None, gate=None,
               residual=None, rows_per_mod=1, n_mod=1, mod_ld=0, rot_cos=None,
               rot_sin=None, n_heads=0, m_rows_dev=None, out_sample_map=None,
-              ldc=None, M=None):
+              out_row_map=None, ldc=None, M=None):
   """C = epilogue(A @ W^T); see include/mdlm_hip.h (mdlm_gemm_bf16)."""
   if M is None:
     M = A.shape[0]
@@ -264,7 +266,7 @@ def gemm_bf16(A, W, C, epilogue=_lib.EPI_STORE, bias=None, gate=None,
        C.data_ptr(), int(ldc), _DT[C.dtype], int(M), N, K, int(epilogue),
        _p(gate), _p(residual), int(rows_per_mod), int(n_mod), int(mod_ld),
        _p(rot_cos), _p(rot_sin), int(n_heads), _p(m_rows_dev),
-       _p(out_sample_map), _stream())
+       _p(out_sample_map), _p(out_row_map), _stream())
   return C
 
 
@@ -272,6 +274,13 @@ def attn_fwd(q, k, vt, out, n_seq, H, L, n_seq_dev=None):
   call('mdlm_attn_fwd', q.data_ptr(), k.data_ptr(), vt.data_ptr(),
        out.data_ptr(), int(n_seq), int(H), int(L), _p(n_seq_dev), _stream())
   return out
+
+
+def masked_row_map(x, active, n_active, L, mask_index, gather, scatter, n_out,
+                   pad=256):
+  call('mdlm_masked_row_map', x.data_ptr(), active.data_ptr(),
+       n_active.data_ptr(), int(L), int(mask_index), int(pad),
+       gather.data_ptr(), scatter.data_ptr(), n_out.data_ptr(), _stream())
 
 
 def gemm_set_tile(force_small):

@@ -146,12 +146,14 @@ def test_cache_policies_and_reference_loop_agree(ops):
   for name, ov in {'sample': ['sampling.cache_policy=sample'],
                    'batch': ['sampling.cache_policy=batch'],
                    'none': ['sampling.cache_policy=none'],
+                   'allrows': ['sampling.masked_rows_only=false'],
                    'loop': ['sampling.fused=false', 'sampling.p_x0_dtype=fp32']}.items():
     model, cfg, _ = make_model(ov)
     model.seed_rng(77)
     outs[name] = (model._sample(num_steps=24).cpu(), int(model.last_nfe.item()))
-  for name in ('batch', 'none', 'loop'):
+  for name in ('batch', 'none', 'loop', 'allrows'):
     assert torch.equal(outs['sample'][0], outs[name][0]), name
+  assert outs['allrows'][1] == outs['sample'][1]
   assert outs['sample'][1] <= outs['batch'][1] <= outs['none'][1]
   assert outs['loop'][1] - outs['batch'][1] in (0, 3)  # final forward may be cached
   assert outs['none'][1] == 3 * 25

@@ -256,6 +256,45 @@ def test_dit_forward_vs_oracle(ops, shape):
   assert torch.equal(out0, out1)
 
 
+def test_masked_row_projection(ops):
+  """Final LN + vocab GEMM restricted to the masked rows of the active samples
+  == the same rows of the all-rows run, bit for bit; other rows untouched."""
+  hidden, heads, blocks, cond, V, L = 128, 2, 2, 64, 300, 256
+  model, _ = _make_model(hidden, heads, blocks, cond, V, seed=6)
+  torch.manual_seed(9)
+  B, mask = 4, V - 1
+  idx = torch.randint(0, V - 1, (B, L))
+  idx[torch.rand(B, L) < 0.4] = mask
+  idx[2] = mask                      # fully masked sample
+  idx[3, :] = 5                      # fully unmasked (inactive below)
+  idx = idx.cuda()
+  z = torch.zeros(B).cuda()
+  full = model.run(idx, z, ops.alloc_logits(B, L, V), sigma_is_zero=True).clone()
+  active = torch.tensor([2, 0, 1, 0], dtype=torch.int32).cuda()
+  n_act = torch.tensor([3], dtype=torch.int32).cuda()
+  n_rows = torch.tensor([3 * L], dtype=torch.int32).cuda()
+  gather = torch.full((B * L + 256,), -9, dtype=torch.int32).cuda()
+  scatter = torch.full((B * L + 256,), -9, dtype=torch.int32).cuda()
+  n_m = torch.zeros(1, dtype=torch.int32).cuda()
+  ops.masked_row_map(idx, active, n_act, L, mask, gather, scatter, n_m)
+  # reference row lists on the host
+  g_ref, s_ref = [], []
+  for i, b in enumerate([2, 0, 1]):
+    for pos in range(L):
+      if idx[b, pos].item() == mask:
+        g_ref.append(i * L + pos); s_ref.append(b * L + pos)
+  n = len(g_ref); npad = (n + 255) // 256 * 256
+  assert n_m.item() == npad
+  assert gather[:n].tolist() == g_ref and scatter[:n].tolist() == s_ref
+  assert (gather[n:npad] == 0).all() and (scatter[n:npad] == -1).all()
+  cache = ops.alloc_logits(B, L, V); cache.fill_(7.0)
+  model.run(idx, z, cache, sigma_is_zero=True, active=active, n_active_dev=n_act,
+            n_rows_dev=n_rows, n_max=B, row_map=(gather, scatter, n_m))
+  m = (idx == mask); m[3] = False
+  assert torch.equal(cache[m], full[m])
+  assert (cache[~m] == 7.0).all()
+
+
 def test_dit_active_compaction_is_batch_invariant(ops):
   """Per-sample evaluation must be bit-identical to the full-batch one."""
   hidden, heads, blocks, cond, V, L = 128, 2, 2, 64, 300, 256
