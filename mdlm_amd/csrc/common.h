@@ -61,8 +61,12 @@ struct Philox {
     unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0x6d646c6du, c3 = 0;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-      unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-      unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      // one 32x32->64 multiply per lane pair (v_mad_u64_u32) instead of a
+      // separate v_mul_hi_u32 + v_mul_lo_u32
+      const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+      const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+      unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+      unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
       unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
       c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
       k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

@@ -359,6 +359,118 @@ __global__ __launch_bounds__(NT) void ddpm_update_kernel(
   }
 }
 
+// Throughput variant of the race (fast_math + in-kernel Philox).  Same draw
+// u_v, same winner up to floating-point near-ties, fewer transcendentals:
+//   argmax_v q_v / g_v,  g_v = 1e-10 - ln(u_v + 1e-10)
+// SRC 1 (logits): q_v = exp(l_v - lse) f  ->  compare in the log2 domain
+//   key_v = l_v log2(e) - log2(g_v)                      (2 x v_log_f32)
+//   key_mask = log2(ms) - log2(g_mask) + lse log2(e) - log2(f)
+// SRC 0 (probabilities): key_v = p_v f / g_v            (v_log_f32 + v_rcp_f32)
+// No NaN ordering (inputs are finite); branch-free running maximum.
+struct FastRace {
+  float best = -INFINITY; int idx = 0x7fffffff;
+  __device__ __forceinline__ void put(float k, int i) {
+    const bool take = k > best;   // ascending i per thread: first index wins ties
+    best = take ? k : best; idx = take ? i : idx;
+  }
+};
+
+template <int SRC>
+__device__ __forceinline__ float fast_key(float x, unsigned rbits, float factor) {
+  const float u = Philox::u01(rbits);
+  const float a = __builtin_amdgcn_logf(u + 1e-10f);              // log2
+  const float g = __builtin_fmaf(-0.6931471805599453f, a, 1e-10f);
+  if constexpr (SRC == 1) return __builtin_fmaf(x, 1.4426950408889634f, -__builtin_amdgcn_logf(g));
+  else return x * factor * __builtin_amdgcn_rcpf(g);
+}
+
+template <typename T, int SRC>
+__global__ __launch_bounds__(NT) void ddpm_update_fast_kernel(
+    const T* __restrict__ src, int64_t ld, const float* __restrict__ lse_arr,
+    const int64_t* __restrict__ x, const float* __restrict__ t, float dt,
+    uint64_t seed, uint64_t offset, int64_t* __restrict__ x_next,
+    int32_t* __restrict__ changed, int L, int V, int mask) {
+  __shared__ float smv[4]; __shared__ int smi[4];
+  constexpr int EPV = vec_traits<T>::EPV;
+  const int64_t r = blockIdx.x;
+  const int64_t tok = x[r];
+  if (tok != mask) {  // carry-over, diffusion.py:609-610
+    if (threadIdx.x == 0) x_next[r] = tok;
+    return;
+  }
+  const int b = (int)(r / L);
+  const float mt = t[b];
+  const float ms = mt - dt;          // diffusion.py:599 (fp32)
+  const float factor = mt - ms;      // diffusion.py:605
+  const T* row = src + r * ld;
+  const uint64_t G = (uint64_t)((V + 3) >> 2);
+  const uint64_t ctr0 = offset + (uint64_t)r * G;
+  // key of the mask column given its random bits (diffusion.py:606: q = ms)
+  auto mask_key = [&](unsigned rbits) -> float {
+    const float u = Philox::u01(rbits);
+    const float g = __builtin_fmaf(-0.6931471805599453f, __builtin_amdgcn_logf(u + 1e-10f), 1e-10f);
+    if constexpr (SRC == 1) {
+      if (!(ms > 0.f)) return -INFINITY;
+      return __builtin_amdgcn_logf(ms) - __builtin_amdgcn_logf(g) +
+             lse_arr[r] * 1.4426950408889634f - __builtin_amdgcn_logf(factor);
+    } else {
+      return ms * __builtin_amdgcn_rcpf(g);
+    }
+  };
+  FastRace fr;
+  if (row_head(row, V) == 0) {
+    const int nvec = V / EPV;
+    const uint4* vp = reinterpret_cast<const uint4*>(row);
+    for (int i = threadIdx.x; i < nvec; i += NT) {
+      float f[EPV];
+      unpack<T>(vp[i], f);
+      const int v0 = i * EPV;
+      float key[EPV];
+#pragma unroll
+      for (int gq = 0; gq < EPV / 4; ++gq) {
+        const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)((v0 >> 2) + gq));
+        key[gq * 4 + 0] = fast_key<SRC>(f[gq * 4 + 0], rn.x, factor);
+        key[gq * 4 + 1] = fast_key<SRC>(f[gq * 4 + 1], rn.y, factor);
+        key[gq * 4 + 2] = fast_key<SRC>(f[gq * 4 + 2], rn.z, factor);
+        key[gq * 4 + 3] = fast_key<SRC>(f[gq * 4 + 3], rn.w, factor);
+        if ((unsigned)(mask - (v0 + gq * 4)) < 4u) {  // rare: the mask column is in this group
+          const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
+          key[gq * 4 + (mask & 3)] = mask_key(rr[mask & 3]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) fr.put(key[k], v0 + k);
+    }
+    for (int v = nvec * EPV + threadIdx.x; v < V; v += NT) {
+      const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)(v >> 2));
+      const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
+      const float k = v == mask ? mask_key(rr[v & 3])
+                                : fast_key<SRC>(elem<T>::load(row + v), rr[v & 3], factor);
+      fr.put(k, v);
+    }
+  } else {
+    for (int g = threadIdx.x; g < (int)G; g += NT) {
+      const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)g);
+      const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int v = g * 4 + k;
+        if (v < V) {
+          const float kk = v == mask ? mask_key(rr[k])
+                                     : fast_key<SRC>(elem<T>::load(row + v), rr[k], factor);
+          fr.put(kk, v);
+        }
+      }
+    }
+  }
+  ArgMax am; am.v = fr.best; am.i = fr.idx;
+  const int best = block_argmax(am, smv, smi);
+  if (threadIdx.x == 0) {
+    x_next[r] = best;
+    if (best != mask && changed) changed[b] = 1;  // benign race: all write 1
+  }
+}
+
 __global__ void philox_uniform_kernel(float* out, int64_t rows, int V,
                                       uint64_t seed, uint64_t offset) {
   const uint64_t G = (uint64_t)((V + 3) >> 2);
@@ -605,7 +717,12 @@ static int launch_update(const void* src, int64_t ld, int dtype, const float* ls
 #define MDLM_UPD(T, FAST, PH) \
   ddpm_update_kernel<T, SRC, FAST, PH><<<rows, NT, 0, s>>>((const T*)src, ld, lse, x, t, dtf, u, seed, offset, x_next, changed, L, V, mask_index)
   const bool ph = (u == nullptr), fast = fast_math != 0;
-  if (dtype == MDLM_F32) {
+  if (ph && fast) {
+    if (dtype == MDLM_F32)
+      ddpm_update_fast_kernel<float, SRC><<<rows, NT, 0, s>>>((const float*)src, ld, lse, x, t, dtf, seed, offset, x_next, changed, L, V, mask_index);
+    else
+      ddpm_update_fast_kernel<bf16_t, SRC><<<rows, NT, 0, s>>>((const bf16_t*)src, ld, lse, x, t, dtf, seed, offset, x_next, changed, L, V, mask_index);
+  } else if (dtype == MDLM_F32) {
     if (ph) { if (fast) MDLM_UPD(float, true, true); else MDLM_UPD(float, false, true); }
     else    { if (fast) MDLM_UPD(float, true, false); else MDLM_UPD(float, false, false); }
   } else {
