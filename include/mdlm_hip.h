@@ -82,9 +82,13 @@ int mdlm_ddpm_cache_update(const void* p_x0, int64_t ld, int dtype,
 
 /* (a)+(b) fused from cached LOGITS: p_x0 = exp(logit - lse) is formed in
  * registers (diffusion.py:602 `.exp()` + 261-277), never written.  lse (B*L)
- * from mdlm_subs_row_lse.  Same sampling semantics as above. */
+ * as from mdlm_subs_row_lse.  fresh (B) int32, optional: samples flagged
+ * non-zero have new logits -- their masked rows' lse is recomputed in-kernel
+ * (and stored to lse) before the race, so no separate lse pass is needed.
+ * Same sampling semantics as above. */
 int mdlm_subs_ddpm_update(const void* logits, int64_t ld, int dtype,
-                          const float* lse, const int64_t* x, const float* t,
+                          float* lse, const int32_t* fresh,
+                          const int64_t* x, const float* t,
                           double dt, const float* u, uint64_t seed,
                           uint64_t offset, int64_t* x_next, int32_t* changed,
                           int B, int L, int V, int mask_index, int fast_math,
@@ -201,10 +205,12 @@ int mdlm_attn_fwd(const void* q, const void* k, const void* vt, void* out,
  * = ascending sample ids with changed != 0, *n_active = n, *n_rows = n*L.
  * all_or_nothing != 0 reproduces the reference policy literally: if any
  * sample changed, every sample is listed.  nfe_accum (optional int64):
- * += n (backbone evaluations, in samples). */
+ * += n (backbone evaluations, in samples).  fresh (optional, B int32):
+ * fresh[b] = 1 if sample b is listed, else 0 (input of mdlm_subs_ddpm_update). */
 int mdlm_compact_active(const int32_t* changed, int32_t* active,
                         int32_t* n_active, int32_t* n_rows, int B, int L,
-                        int all_or_nothing, int64_t* nfe_accum, void* stream);
+                        int all_or_nothing, int64_t* nfe_accum, int32_t* fresh,
+                        void* stream);
 
 /* Row lists of the MASKED rows of the active samples: only those rows need
  * logits (an unmasked token is carried over, diffusion.py:609-610, and SUBS

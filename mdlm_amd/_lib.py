@@ -22,7 +22,7 @@ SIGNATURES = {
   'mdlm_subs_argmax': [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp],
   'mdlm_ddpm_cache_update': [_vp, _i64, _i32, _vp, _vp, _dbl, _vp, _u64, _u64,
                              _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
-  'mdlm_subs_ddpm_update': [_vp, _i64, _i32, _vp, _vp, _vp, _dbl, _vp, _u64,
+  'mdlm_subs_ddpm_update': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _dbl, _vp, _u64,
                             _u64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
   'mdlm_philox_uniform': [_vp, _i64, _i32, _u64, _u64, _vp],
   'mdlm_q_xt': [_vp, _vp, _vp, _u64, _u64, _vp, _i32, _i32, _i32, _vp],
@@ -40,7 +40,7 @@ SIGNATURES = {
                      _vp, _vp],
   'mdlm_attn_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
   'mdlm_gemm_set_tile': [_i32],
-  'mdlm_compact_active': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
+  'mdlm_compact_active': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -24,6 +24,8 @@ namespace mdlm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int AT = 256;          // threads: 4 waves x 32 query rows
 constexpr int QB = 128;          // query rows per workgroup
@@ -35,12 +37,16 @@ constexpr int KV_TILE = KB * HD * 2;  // 8 KiB
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+// QT = 32-row query tiles per wave: 2 when L % 256 == 0 (K / V^T fragments
+// are then read once for 64 query rows), else 1.
+template <int QT>
 __global__ __launch_bounds__(AT, 2) void attn_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
     const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, int H, int L,
     const int32_t* __restrict__ n_seq_dev) {
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE];  // K0 K1 V0 V1
-  const int qblocks = L / QB;
+  constexpr int QBQ = QB * QT;           // query rows per workgroup
+  const int qblocks = L / QBQ;
   const int bid = blockIdx.x;
   const int qb = bid % qblocks;
   const int bh = bid / qblocks;        // seq * H + head
@@ -50,17 +56,19 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
-  const int q0 = qb * QB + wid * 32;
+  const int q0 = qb * QBQ + wid * (32 * QT);
 
   const bf16_t* qp = q + ((int64_t)bh * L + q0 + r) * HD;
   const bf16_t* kp = k + (int64_t)bh * L * HD;
   const bf16_t* vp = vt + (int64_t)bh * HD * L;
 
   // Q fragments: B operand, lane (q=r, half hh) holds Q[q][16*ks + 8*hh + j]
-  bf16x8 qf[4];
+  bf16x8 qf[QT][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-    qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16 + hh * 8);
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[t][ks] = *reinterpret_cast<const bf16x8*>(qp + t * 32 * HD + ks * 16 + hh * 8);
 
   // staging: per tile 8 KiB for K and 8 KiB for V^T = 8 + 8 wave-instructions;
   // wave w issues chunks {w, w+4}.  chunk c -> tile rows c*8..c*8+7.
@@ -98,95 +106,121 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_kernel(
       voff[dt][c4] = row * 128 + ((((c4 >> 1) * 4 + (c4 & 1) * 2 + hh) ^ ((row >> 1) & 7)) * 16);
   }
 
-  f32x16 oacc[2];
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 oacc[QT][2];
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int t = 0; t < QT; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+    for (int dt = 0; dt < 2; ++dt) oacc[t][dt] = zero16;
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) { m_run[t] = -INFINITY; l_run[t] = 0.f; }
   const float sc = 0.125f * 1.4426950408889634f;  // softmax scale * log2(e)
 
   const int NT = L / KB;
   stage(0, 0);
   __syncthreads();
-  for (int t = 0; t < NT; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < NT) stage(cur ^ 1, (t + 1) * KB);
+  for (int tt = 0; tt < NT; ++tt) {
+    const int cur = tt & 1;
+    if (tt + 1 < NT) stage(cur ^ 1, (tt + 1) * KB);
     const char* Kt = smem + cur * KV_TILE;
     const char* Vt = smem + (2 + cur) * KV_TILE;
 
-    // ---- S^T = K Q^T ----------------------------------------------------
-    f32x16 sacc[2];
-#pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sacc[kt2][e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kt + koff[kt2][ks]);
-        sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt2], 0, 0, 0);
-      }
-    }
-    // ---- online softmax (per query column; keys in-lane + other half) ----
-    float mx = sacc[0][0];
-#pragma unroll
-    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sacc[0][e]);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[1][e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx * sc);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
-    float lsum = 0.f;
+    // ---- S^T = K Q^T (K fragments shared by the QT query tiles) -----------
+    // all eight K fragments are requested before the first MFMA, and the V^T
+    // fragments right behind them, so that their LDS latency is covered by the
+    // QK^T MFMAs and the softmax instead of stalling every MFMA pair
+    bf16x8 kf[2][4], vf[2][4];
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float p = exp2f(sacc[kt2][e] * sc - m_new);
-        sacc[kt2][e] = p;
-        lsum += p;
-      }
-    l_run = l_run * alpha + lsum;
+      for (int ks = 0; ks < 4; ++ks)
+        kf[kt2][ks] = *reinterpret_cast<const bf16x8*>(Kt + koff[kt2][ks]);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
-    // ---- P^T fragments straight from the accumulators --------------------
-    bf16x8 pf[4];
+      for (int c4 = 0; c4 < 4; ++c4)
+        vf[dt][c4] = *reinterpret_cast<const bf16x8*>(Vt + voff[dt][c4]);
+    f32x16 sacc[QT][2];
 #pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) {
-      const int kt2 = c4 >> 1, s = c4 & 1;
-      const uint4 pk = make_uint4(
-        pack_bf16x2(sacc[kt2][8 * s + 0], sacc[kt2][8 * s + 1]),
-        pack_bf16x2(sacc[kt2][8 * s + 2], sacc[kt2][8 * s + 3]),
-        pack_bf16x2(sacc[kt2][8 * s + 4], sacc[kt2][8 * s + 5]),
-        pack_bf16x2(sacc[kt2][8 * s + 6], sacc[kt2][8 * s + 7]));
-      pf[c4] = __builtin_bit_cast(bf16x8, pk);
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+          sacc[t][kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            kf[kt2][ks], qf[t][ks], ks == 0 ? zero16 : sacc[t][kt2], 0, 0, 0);
+    // ---- online softmax (per query column; keys in-lane + other half) ----
+    bf16x8 pf[QT][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      float mx = sacc[t][0][0];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sacc[t][0][e]);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[t][1][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[t], mx * sc);
+      // O and l only need rescaling when some row's running max moved
+      if (__any(m_new > m_run[t])) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+        l_run[t] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[t][dt][e] *= alpha;
+        m_run[t] = m_new;
+      }
+      // p = exp2(s * sc - m): packed fma / add (two elements per VALU
+      // instruction), one v_exp_f32 per element, one v_cvt_pk_bf16_f32 per pair
+      f32x2 lsum2 = {0.f, 0.f};
+      const f32x2 sc2 = {sc, sc}, nm2 = {-m_new, -m_new};
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const int kt2 = c4 >> 1, s8 = (c4 & 1) * 8;
+        unsigned pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f32x2 x = {sacc[t][kt2][s8 + 2 * e], sacc[t][kt2][s8 + 2 * e + 1]};
+          x = __builtin_elementwise_fma(x, sc2, nm2);
+          f32x2 pp = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+          lsum2 += pp;
+          const bf16x2 pb = __builtin_convertvector(pp, bf16x2);
+          pk[e] = __builtin_bit_cast(unsigned, pb);
+        }
+        const uint4 pk4 = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        pf[t][c4] = __builtin_bit_cast(bf16x8, pk4);
+      }
+      l_run[t] += lsum2[0] + lsum2[1];
     }
-    // ---- O^T += V^T P^T ----------------------------------------------------
+    // ---- O^T += V^T P^T (V^T fragments shared by the QT query tiles) -------
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int c4 = 0; c4 < 4; ++c4) {
-        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vt + voff[dt][c4]);
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c4], oacc[dt], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+          oacc[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][c4], pf[t][c4], oacc[t][dt], 0, 0, 0);
       }
     __syncthreads();
   }
 
   // ---- normalise and store O[q, head*64 + d] ------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.f / l_tot;
-  bf16_t* op = out + ((int64_t)seq * L + q0 + r) * ((int64_t)H * HD) + head * HD;
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int t = 0; t < QT; ++t) {
+    const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32);
+    const float inv = 1.f / l_tot;
+    bf16_t* op = out + ((int64_t)seq * L + q0 + t * 32 + r) * ((int64_t)H * HD) + head * HD;
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int d = dt * 32 + 8 * g4 + 4 * hh;
-      *reinterpret_cast<uint2*>(op + d) = make_uint2(
-        pack_bf16x2(oacc[dt][4 * g4 + 0] * inv, oacc[dt][4 * g4 + 1] * inv),
-        pack_bf16x2(oacc[dt][4 * g4 + 2] * inv, oacc[dt][4 * g4 + 3] * inv));
-    }
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d = dt * 32 + 8 * g4 + 4 * hh;
+        *reinterpret_cast<uint2*>(op + d) = make_uint2(
+          pack_bf16x2(oacc[t][dt][4 * g4 + 0] * inv, oacc[t][dt][4 * g4 + 1] * inv),
+          pack_bf16x2(oacc[t][dt][4 * g4 + 2] * inv, oacc[t][dt][4 * g4 + 3] * inv));
+      }
+  }
 }
 
 }  // namespace mdlm
@@ -200,10 +234,15 @@ extern "C" int mdlm_attn_fwd(const void* q, const void* k, const void* vt,
   MDLM_CHECK_ARG(n_seq >= 0 && H > 0 && L > 0 && L % QB == 0, "attn_fwd: L=%d must be a multiple of %d", L, QB);
   MDLM_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) == 0, "attn_fwd: buffers must be 16-byte aligned");
   if (n_seq == 0) return 0;
-  const int64_t blocks = (int64_t)n_seq * H * (L / QB);
+  const int qt = (L % (2 * QB) == 0) ? 2 : 1;
+  const int64_t blocks = (int64_t)n_seq * H * (L / (QB * qt));
   MDLM_CHECK_ARG(blocks < (1ll << 31), "attn_fwd: too many blocks");
-  attn_fwd_kernel<<<(unsigned)blocks, AT, 0, (hipStream_t)stream>>>(
-    (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, L, n_seq_dev);
+  if (qt == 2)
+    attn_fwd_kernel<2><<<(unsigned)blocks, AT, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, L, n_seq_dev);
+  else
+    attn_fwd_kernel<1><<<(unsigned)blocks, AT, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, L, n_seq_dev);
   MDLM_LAUNCH_CHECK();
   return 0;
 }

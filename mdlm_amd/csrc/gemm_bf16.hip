@@ -45,7 +45,7 @@ struct GemmArgs {
   const int32_t* out_row_map;
   const float* rot_cos; const float* rot_sin; int n_heads;
   const int32_t* m_rows_dev;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, seq_len;
   int vec_ok;  // ldc / alignment allow 16-byte row stores
   int dbg;     // timing experiments only (bit 1: skip the epilogue)
 };
@@ -65,24 +65,20 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 
 __device__ __forceinline__ float bf16_round(float x) { return bf16_to_f32(f32_to_bf16(x)); }
 
-// 16-byte row store of the epilogue.  dbg bits are timing experiments only:
-// 4 = drop the store, 8 = non-temporal, 16 = sc1 (write-through, not kept in L2).
+// 16-byte row store of the epilogue.  bf16 outputs (q/k, MLP hidden, logits)
+// are written once and read by a later kernel: non-temporal stores keep them
+// from displacing the A/W panels in L2 (measured -7..-14 % per launch); the
+// fp32 residual stream is read-modify-written in place and stays plain.
+// dbg bits are timing experiments only: 4 = drop the store, 8 = flip the
+// temporal hint.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
 __device__ __forceinline__ void store16(void* p, uint4 v, int dbg) {
   if (dbg & 4) return;
-  if (dbg & 8) {
-    __builtin_nontemporal_store(v.x, reinterpret_cast<unsigned*>(p));
-    __builtin_nontemporal_store(v.y, reinterpret_cast<unsigned*>(p) + 1);
-    __builtin_nontemporal_store(v.z, reinterpret_cast<unsigned*>(p) + 2);
-    __builtin_nontemporal_store(v.w, reinterpret_cast<unsigned*>(p) + 3);
-  } else if (dbg & 16) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 vv = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(vv) : "memory");
-  } else {
-    *reinterpret_cast<uint4*>(p) = v;
-  }
+  const u32x4 vv = {v.x, v.y, v.z, v.w};
+  if (NT != ((dbg & 8) != 0)) __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(p));
+  else *reinterpret_cast<u32x4*>(p) = vv;
 }
-
 
 // Epilogue of one 64x64 wave sub-tile.  SWAPPED accumulators (see header):
 // acc(m, n)[j] = C[grow0 + m*16 + fr][gcol0 + n*16 + fq*4 + j].
@@ -152,7 +148,7 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + (lane >> 3), ch = lane & 7;
       const uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((ch ^ (row & 7)) * 16));
-      store16(qb + row * 64 + ch * 8, v, g.dbg);
+      store16<true>(qb + row * 64 + ch * 8, v, g.dbg);
     }
     return;
   } else {
@@ -217,7 +213,7 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
           const int row = it * 8 + (lane >> 3), ch = lane & 7;
           const uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((ch ^ (row & 7)) * 16));
           const int64_t dr = dst_row(row);
-          if (dr >= 0) store16(Cp0 + dr * g.ldc + ch * 8, v, g.dbg);
+          if (dr >= 0) store16<true>(Cp0 + dr * g.ldc + ch * 8, v, g.dbg);
         }
       } else {
         // fp32 tile [64][64], 16-B chunk index swizzled by (row & 15)
@@ -247,7 +243,7 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
             v.z = rs.z + gt.z * v.z; v.w = rs.w + gt.w * v.w;
           }
           const int64_t dr = dst_row(row);
-          if (dr >= 0) store16(Cp0 + dr * g.ldc + ch * 4, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), g.dbg);
+          if (dr >= 0) store16<false>(Cp0 + dr * g.ldc + ch * 4, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), g.dbg);
         }
       }
     } else {
@@ -288,40 +284,37 @@ void gemm_bf16_kernel(GemmArgs g) {
   constexpr int A_CH = (TBM / 8) / NW, B_CH = (TBN / 8) / NW;  // 1 KiB chunks per wave
   constexpr int GROUP_M = 1024 / TBM;  // 1024 rows of A (1.5 MiB at K=768) per group
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // ---- XCD-aware tile mapping ------------------------------------------
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid / WN, wc = wid - wr * WN;
+  // ---- XCD-aware, persistent tile walk -----------------------------------
+  // Workgroup b belongs to XCD group b & 7 and walks that group's tile
+  // sequence (groups of 1024 A rows x all N tiles, N outer) with stride
+  // gridDim/8: the workgroups resident on one XCD work on neighbouring tiles
+  // (shared A panels in its L2).  With grid = 8 * seq_len every workgroup
+  // owns one tile; with a CU-sized grid the kernel is persistent and the
+  // stores of tile i drain under the main loop of tile i+1.
   const int bid = blockIdx.x;
   const int xcd = bid & 7;
-  const int j = bid >> 3;
+  const int slots = gridDim.x >> 3;
   const int per_group = GROUP_M * g.tiles_n;
+  bool first_tile = true;
+  for (int j = bid >> 3; j < g.seq_len; j += slots) {
   const int gl = j / per_group;
   const int rem = j - gl * per_group;
   const int tn = rem / GROUP_M;
   const int mi = rem - tn * GROUP_M;
   const int tm = (gl * 8 + xcd) * GROUP_M + mi;
-  if (tm >= g.tiles_m) return;
+  if (tm >= g.tiles_m) continue;
   const int64_t m0 = (int64_t)tm * TBM;
-  if (g.m_rows_dev && m0 >= (int64_t)*g.m_rows_dev) return;
+  if (g.m_rows_dev && m0 >= (int64_t)*g.m_rows_dev) continue;
   const int n0 = tn * TBN;
+  // the previous tile's epilogue staged through LDS regions this tile's DMA
+  // overwrites: every wave must be done reading them
+  if (!first_tile) __syncthreads();
+  first_tile = false;
 
-  // Phase stagger (timing experiment, dbg >> 8 = delay in ~1 us units): all
-  // tiles take the same time, so co-scheduled workgroups otherwise run their
-  // store-heavy epilogues in lockstep; delaying half of the first resident set
-  // once puts half of the chip's epilogues under the other half's main loops.
-  if (g.dbg >> 8) {
-    constexpr int RES = (NW == 8) ? 256 : 512;  // first resident set
-    const bool late = (NW == 8) ? ((bid >> 3) & 1) : (bid >= 256);
-    if (g.dbg & 32) {  // pseudo-random phase for every workgroup of the first set
-      const int n = (int)(((unsigned)bid * 2654435761u) >> 16) % (g.dbg >> 8);
-      if (bid < RES)
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
-    } else if (bid < RES && late)
-      for (int i = 0; i < (g.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(32);
-  }
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid / WN, wc = wid - wr * WN;
 
   // ---- staging addresses -------------------------------------------------
   // chunk c = i*NW + wid covers tile rows c*8 .. c*8+7; lane -> (row lane>>3,
@@ -411,12 +404,13 @@ void gemm_bf16_kernel(GemmArgs g) {
   }
 
   // ---- epilogue: MT/4 passes of a 64x64 sub-tile through this wave's LDS ----
-  if (g.dbg & 2) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(g.C)[0] = 1.f; return; }
+  if (g.dbg & 2) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(g.C)[0] = 1.f; continue; }
   char* ep = smem + wid * 16384;
   const int gcol0 = n0 + wc * 64;
   const int64_t growW = m0 + wr * (MT * 16);
   epilogue_64x64<EPI, TC, MT, 0>(acc, ep, growW, gcol0, g, lane);
   if constexpr (MT == 8) epilogue_64x64<EPI, TC, MT, 1>(acc, ep, growW + 64, gcol0, g, lane);
+  }  // tile loop
 }
 
 template <int EPI, typename TC, int WM, int WN, int MT>
@@ -436,8 +430,13 @@ static int launch_cfg(GemmArgs g, hipStream_t s) {
   g.tiles_n = (g.N + TBN - 1) / TBN;
   const int groups = (g.tiles_m + GROUP_M - 1) / GROUP_M;
   const int gl = (groups + 7) / 8;
-  const int64_t grid = (int64_t)8 * gl * GROUP_M * g.tiles_n;
+  g.seq_len = gl * GROUP_M * g.tiles_n;
+  int64_t grid = (int64_t)8 * g.seq_len;
   if (grid >= (1ll << 31)) { set_error("gemm: grid too large"); return -1; }
+  // persistent launch: one workgroup per CU for the 128 KiB-LDS tile, two for
+  // the 64 KiB one (dbg bit 6 = 64 restores one tile per workgroup)
+  const int64_t resident = (LDS > 80 * 1024) ? 256 : 512;
+  if (!(g.dbg & 64) && grid > resident) grid = resident;
   gemm_bf16_kernel<EPI, TC, WM, WN, MT><<<(unsigned)grid, 64 * WM * WN, LDS, s>>>(g);
   MDLM_LAUNCH_CHECK();
   return 0;

@@ -282,7 +282,8 @@ __device__ __forceinline__ float q_of(float x, int v, int mask, float lse,
 
 template <typename T, int SRC, bool FAST, bool PHILOX>
 __global__ __launch_bounds__(NT) void ddpm_update_kernel(
-    const T* __restrict__ src, int64_t ld, const float* __restrict__ lse_arr,
+    const T* __restrict__ src, int64_t ld, float* __restrict__ lse_arr,
+    const int32_t* __restrict__ fresh,
     const int64_t* __restrict__ x, const float* __restrict__ t, float dt,
     const float* __restrict__ u, uint64_t seed, uint64_t offset,
     int64_t* __restrict__ x_next, int32_t* __restrict__ changed, int L, int V,
@@ -299,8 +300,17 @@ __global__ __launch_bounds__(NT) void ddpm_update_kernel(
   const float mt = t[b];
   const float ms = mt - dt;          // diffusion.py:599 (fp32)
   const float factor = mt - ms;      // diffusion.py:605 (not fp32(dt))
-  const float lse = SRC == 1 ? lse_arr[r] : 0.f;
   const T* row = src + r * ld;
+  float lse = 0.f;
+  if constexpr (SRC == 1) {
+    if (fresh && fresh[b]) {  // logits of this sample are new: (re)compute the row lse
+      __shared__ float sml[9];
+      lse = subs_row_lse<T>(row, V, mask, sml);
+      if (threadIdx.x == 0) lse_arr[r] = lse;
+    } else {
+      lse = lse_arr[r];
+    }
+  }
   ArgMax am;
   const uint64_t G = (uint64_t)((V + 3) >> 2);
   const uint64_t ctr0 = offset + (uint64_t)r * G;
@@ -386,7 +396,8 @@ __device__ __forceinline__ float fast_key(float x, unsigned rbits, float factor)
 
 template <typename T, int SRC>
 __global__ __launch_bounds__(NT) void ddpm_update_fast_kernel(
-    const T* __restrict__ src, int64_t ld, const float* __restrict__ lse_arr,
+    const T* __restrict__ src, int64_t ld, float* __restrict__ lse_arr,
+    const int32_t* __restrict__ fresh,
     const int64_t* __restrict__ x, const float* __restrict__ t, float dt,
     uint64_t seed, uint64_t offset, int64_t* __restrict__ x_next,
     int32_t* __restrict__ changed, int L, int V, int mask) {
@@ -405,6 +416,16 @@ __global__ __launch_bounds__(NT) void ddpm_update_fast_kernel(
   const T* row = src + r * ld;
   const uint64_t G = (uint64_t)((V + 3) >> 2);
   const uint64_t ctr0 = offset + (uint64_t)r * G;
+  float lse_r = 0.f;
+  if constexpr (SRC == 1) {
+    if (fresh && fresh[b]) {  // new logits: one extra pass for the row lse (L2-warm after it)
+      __shared__ float sml[9];
+      lse_r = subs_row_lse<T>(row, V, mask, sml);
+      if (threadIdx.x == 0) lse_arr[r] = lse_r;
+    } else {
+      lse_r = lse_arr[r];
+    }
+  }
   // key of the mask column given its random bits (diffusion.py:606: q = ms)
   auto mask_key = [&](unsigned rbits) -> float {
     const float u = Philox::u01(rbits);
@@ -412,7 +433,7 @@ __global__ __launch_bounds__(NT) void ddpm_update_fast_kernel(
     if constexpr (SRC == 1) {
       if (!(ms > 0.f)) return -INFINITY;
       return __builtin_amdgcn_logf(ms) - __builtin_amdgcn_logf(g) +
-             lse_arr[r] * 1.4426950408889634f - __builtin_amdgcn_logf(factor);
+             lse_r * 1.4426950408889634f - __builtin_amdgcn_logf(factor);
     } else {
       return ms * __builtin_amdgcn_rcpf(g);
     }
@@ -550,7 +571,8 @@ __global__ void compact_active_kernel(const int32_t* __restrict__ changed,
                                       int32_t* __restrict__ n_active,
                                       int32_t* __restrict__ n_rows, int B, int L,
                                       int all_or_nothing,
-                                      int64_t* __restrict__ nfe_accum) {
+                                      int64_t* __restrict__ nfe_accum,
+                                      int32_t* __restrict__ fresh) {
   // single wave; ordered compaction via ballot, 64 samples per pass
   bool any = false;
   if (all_or_nothing) {
@@ -565,6 +587,7 @@ __global__ void compact_active_kernel(const int32_t* __restrict__ changed,
     const bool on = b < B && (any || changed[b] != 0);
     const unsigned long long m = __ballot(on);
     if (on) active[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = b;
+    if (fresh && b < B) fresh[b] = on ? 1 : 0;
     base += __popcll(m);
   }
   if (threadIdx.x == 0) {
@@ -695,7 +718,8 @@ extern "C" int mdlm_subs_argmax(const void* logits, int64_t ld, int dtype,
 }
 
 template <int SRC>
-static int launch_update(const void* src, int64_t ld, int dtype, const float* lse,
+static int launch_update(const void* src, int64_t ld, int dtype, float* lse,
+                         const int32_t* fresh,
                          const int64_t* x, const float* t, double dt,
                          const float* u, uint64_t seed, uint64_t offset,
                          int64_t* x_next, int32_t* changed, int B, int L, int V,
@@ -715,13 +739,13 @@ static int launch_update(const void* src, int64_t ld, int dtype, const float* ls
   const unsigned rows = (unsigned)((int64_t)B * L);
   const float dtf = (float)dt;  // python float -> fp32 scalar, as torch does
 #define MDLM_UPD(T, FAST, PH) \
-  ddpm_update_kernel<T, SRC, FAST, PH><<<rows, NT, 0, s>>>((const T*)src, ld, lse, x, t, dtf, u, seed, offset, x_next, changed, L, V, mask_index)
+  ddpm_update_kernel<T, SRC, FAST, PH><<<rows, NT, 0, s>>>((const T*)src, ld, lse, fresh, x, t, dtf, u, seed, offset, x_next, changed, L, V, mask_index)
   const bool ph = (u == nullptr), fast = fast_math != 0;
   if (ph && fast) {
     if (dtype == MDLM_F32)
-      ddpm_update_fast_kernel<float, SRC><<<rows, NT, 0, s>>>((const float*)src, ld, lse, x, t, dtf, seed, offset, x_next, changed, L, V, mask_index);
+      ddpm_update_fast_kernel<float, SRC><<<rows, NT, 0, s>>>((const float*)src, ld, lse, fresh, x, t, dtf, seed, offset, x_next, changed, L, V, mask_index);
     else
-      ddpm_update_fast_kernel<bf16_t, SRC><<<rows, NT, 0, s>>>((const bf16_t*)src, ld, lse, x, t, dtf, seed, offset, x_next, changed, L, V, mask_index);
+      ddpm_update_fast_kernel<bf16_t, SRC><<<rows, NT, 0, s>>>((const bf16_t*)src, ld, lse, fresh, x, t, dtf, seed, offset, x_next, changed, L, V, mask_index);
   } else if (dtype == MDLM_F32) {
     if (ph) { if (fast) MDLM_UPD(float, true, true); else MDLM_UPD(float, false, true); }
     else    { if (fast) MDLM_UPD(float, true, false); else MDLM_UPD(float, false, false); }
@@ -740,17 +764,18 @@ extern "C" int mdlm_ddpm_cache_update(const void* p_x0, int64_t ld, int dtype,
                                       int64_t* x_next, int32_t* changed, int B,
                                       int L, int V, int mask_index, int fast_math,
                                       void* stream) {
-  return launch_update<0>(p_x0, ld, dtype, nullptr, x, t, dt, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
+  return launch_update<0>(p_x0, ld, dtype, nullptr, nullptr, x, t, dt, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
 }
 
 extern "C" int mdlm_subs_ddpm_update(const void* logits, int64_t ld, int dtype,
-                                     const float* lse, const int64_t* x,
+                                     float* lse, const int32_t* fresh,
+                                     const int64_t* x,
                                      const float* t, double dt, const float* u,
                                      uint64_t seed, uint64_t offset,
                                      int64_t* x_next, int32_t* changed, int B,
                                      int L, int V, int mask_index, int fast_math,
                                      void* stream) {
-  return launch_update<1>(logits, ld, dtype, lse, x, t, dt, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
+  return launch_update<1>(logits, ld, dtype, lse, fresh, x, t, dt, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
 }
 
 extern "C" int mdlm_philox_uniform(float* out, int64_t rows, int V, uint64_t seed,
@@ -802,9 +827,10 @@ extern "C" int mdlm_nll_sums(const float* nll, const float* attn_mask,
 extern "C" int mdlm_compact_active(const int32_t* changed, int32_t* active,
                                    int32_t* n_active, int32_t* n_rows, int B,
                                    int L, int all_or_nothing,
-                                   int64_t* nfe_accum, void* stream) {
+                                   int64_t* nfe_accum, int32_t* fresh,
+                                   void* stream) {
   MDLM_CHECK_ARG(changed && active && n_active && n_rows && B >= 0 && L > 0, "compact_active: bad args");
-  compact_active_kernel<<<1, 64, 0, ST(stream)>>>(changed, active, n_active, n_rows, B, L, all_or_nothing, nfe_accum);
+  compact_active_kernel<<<1, 64, 0, ST(stream)>>>(changed, active, n_active, n_rows, B, L, all_or_nothing, nfe_accum, fresh);
   MDLM_LAUNCH_CHECK();
   return 0;
 }

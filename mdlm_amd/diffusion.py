@@ -245,12 +245,12 @@ class Diffusion(_Base):
       n_active=torch.zeros(1, **i32), n_rows=torch.zeros(1, **i32),
       nfe=torch.zeros(1, dtype=torch.int64, device=dev),
       gather=torch.zeros(B * Lq + 256, **i32), scatter=torch.zeros(B * Lq + 256, **i32),
-      n_mrows=torch.zeros(1, **i32),
+      n_mrows=torch.zeros(1, **i32), fresh=torch.ones(B, **i32),
       zeros=torch.zeros(B, dtype=torch.float32, device=dev))
     self._state = st
     return st
 
-  def _refresh_cache(self, st, x, sigma=None):
+  def _refresh_cache(self, st, x, sigma=None, want_lse=False):
     """Evaluate the backbone for the samples whose tokens changed since their
     cached logits were computed (device-side replacement of the host decision
     at diffusion.py:682-685) and refresh their row lse."""
@@ -261,7 +261,7 @@ class Diffusion(_Base):
       aon = self.config.sampling.get('cache_policy', 'sample') == 'batch'
       ops.compact_active(st['changed'], st['active'], st['n_active'],
                          st['n_rows'], Lq, all_or_nothing=aon,
-                         nfe_accum=st['nfe'])
+                         nfe_accum=st['nfe'], fresh=st['fresh'])
       row_map = None
       if self.config.sampling.get('masked_rows_only', True) and (B * Lq) % 256 == 0:
         # only masked rows need logits: carry-over / SUBS ignore the others
@@ -271,15 +271,18 @@ class Diffusion(_Base):
       self.backbone.run(x, st['zeros'], st['cache'], sigma_is_zero=True,
                         active=st['active'], n_active_dev=st['n_active'],
                         n_rows_dev=st['n_rows'], n_max=B, row_map=row_map)
-      ops.subs_row_lse(st['cache'], x, self.mask_index, out=st['lse'],
-                       sample_map=st['active'], L=Lq, n_rows_dev=st['n_rows'])
+      # the row lse of the refreshed samples is computed inside the update
+      # kernel (`fresh` flags); a separate pass only when asked for
+      if want_lse:
+        ops.subs_row_lse(st['cache'], x, self.mask_index, out=st['lse'],
+                         sample_map=st['active'], L=Lq, n_rows_dev=st['n_rows'])
     else:
       # time conditioning: sigma changes every step, no caching at all
       st['nfe'] += B
       sg = st['zeros'] if sigma is None else self._process_sigma(sigma)
       self.backbone.run(x, sg, st['cache'],
                         sigma_is_zero=not self.time_conditioning)
-      ops.subs_row_lse(st['cache'], x, self.mask_index, out=st['lse'])
+      st['fresh'].fill_(1)
 
   def _fused_step(self, st, x, x_next, t_vec, dt, sigma=None):
     self._refresh_cache(st, x, sigma)
@@ -287,7 +290,7 @@ class Diffusion(_Base):
     seed, off = self._draw(B * Lq * ((self.vocab_size + 3) // 4))
     ops.subs_ddpm_update(
       st['cache'], st['lse'], x, t_vec, dt, self.mask_index, seed=seed,
-      offset=off, changed=st['changed'], x_next=x_next,
+      offset=off, changed=st['changed'], x_next=x_next, fresh=st['fresh'],
       fast_math=bool(self.config.sampling.get('fast_math', False)))
 
   @torch.no_grad()

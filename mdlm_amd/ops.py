@@ -131,7 +131,8 @@ def ddpm_cache_update(p_x0, x, t, dt, mask_index, u=None, seed=0, offset=0,
 
 
 def subs_ddpm_update(logits, lse, x, t, dt, mask_index, u=None, seed=0,
-                     offset=0, changed=None, fast_math=False, x_next=None):
+                     offset=0, changed=None, fast_math=False, x_next=None,
+                     fresh=None):
   """(a)+(b) fused from raw logits + row lse."""
   lg, rows, V, ld = _rows2d(logits, 'logits')
   x = _dev(x, 'x', torch.int64).contiguous()
@@ -146,7 +147,7 @@ def subs_ddpm_update(logits, lse, x, t, dt, mask_index, u=None, seed=0,
   if x_next is None:
     x_next = torch.empty_like(x)
   call('mdlm_subs_ddpm_update', lg.data_ptr(), ld, _DT[lg.dtype],
-       lse.data_ptr(), x.data_ptr(), tt.data_ptr(), float(dt), _p(u),
+       lse.data_ptr(), _p(fresh), x.data_ptr(), tt.data_ptr(), float(dt), _p(u),
        int(seed), int(offset), x_next.data_ptr(), _p(changed), B, L, V,
        int(mask_index), int(bool(fast_math)), _stream())
   return x_next
@@ -202,10 +203,10 @@ def nll_sums(nll, attn_mask=None, sums=None):
 
 
 def compact_active(changed, active, n_active, n_rows, L, all_or_nothing=False,
-                   nfe_accum=None):
+                   nfe_accum=None, fresh=None):
   call('mdlm_compact_active', changed.data_ptr(), active.data_ptr(),
        n_active.data_ptr(), n_rows.data_ptr(), changed.numel(), int(L),
-       int(bool(all_or_nothing)), _p(nfe_accum), _stream())
+       int(bool(all_or_nothing)), _p(nfe_accum), _p(fresh), _stream())
 
 
 # ---------------------------------------------------------------- DiT ops

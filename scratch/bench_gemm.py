@@ -36,5 +36,5 @@ def run(M, mode):
   res['vocab'] = (bench(lambda: ops.gemm_bf16(h, Wv, logits, EPI_STORE, bias=bv, rows_per_mod=L, ldc=logits.stride(-2)), iters=5), 2 * M * V * D)
   print(f'M={M} mode={mode}: ' + '  '.join(f'{k} {t*1e3:7.1f}us {f/t/1e9:6.0f}TF' for k, (t, f) in res.items()))
 for M in (65536,):
-  for mode in (0, 0x620, 0xC20, 1, 0x621, 0xC21, 0x1821):
+  for mode in (0, 0, 2, 4, 8):
     run(M, mode)

@@ -256,6 +256,30 @@ def test_fused_update_from_logits(ops, dtype):
   assert _near_tie_only(rp, xp.cpu(), refp)
 
 
+@pytest.mark.parametrize('fast', [False, True])
+def test_fused_update_computes_lse_for_fresh_samples(ops, fast):
+  """`fresh` samples get their row lse computed inside the update kernel:
+  identical tokens and identical lse to the two-kernel sequence."""
+  torch.manual_seed(11)
+  B, L = 3, 5
+  dl = ops.alloc_logits(B, L, V_OWT, torch.bfloat16)
+  dl.copy_((torch.randn(B, L, V_OWT) * 3).bfloat16())
+  x = torch.full((B, L), MASK_OWT); x[1, 1] = 9
+  t = torch.tensor([0.6, 0.3, 0.9]).cuda()
+  lse_ref = ops.subs_row_lse(dl, x.cuda(), MASK_OWT)
+  ref = ops.subs_ddpm_update(dl, lse_ref, x.cuda(), t, 0.2, MASK_OWT, seed=4, offset=8,
+                             fast_math=fast)
+  # sample 1 is not fresh: it must keep using the lse that is already there
+  lse = torch.full_like(lse_ref, float('nan'))
+  lse[L:2 * L] = lse_ref[L:2 * L]
+  fresh = torch.tensor([1, 0, 1], dtype=torch.int32).cuda()
+  got = ops.subs_ddpm_update(dl, lse, x.cuda(), t, 0.2, MASK_OWT, seed=4, offset=8,
+                             fast_math=fast, fresh=fresh)
+  assert torch.equal(got, ref)
+  m = (x == MASK_OWT).view(-1).cuda()
+  assert torch.equal(lse[m], lse_ref[m])
+
+
 # ------------------------------------------------------------ (c1) q_xt
 def test_q_xt_golden_and_philox(ops):
   g = _g('g3_qxt.npz')
