@@ -138,6 +138,7 @@ def main():
   ap.add_argument('--cache-policy', default='sample', choices=['sample', 'batch', 'none'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-policy-compare', action='store_true')
+  ap.add_argument('--no-eval', action='store_true')
   args = ap.parse_args()
 
   rank, local_rank, world = mdist.init()
@@ -165,7 +166,8 @@ def main():
   for _ in range(args.warmup):
     model.restore_model_and_sample(num_steps=args.T)
   sync_all()
-  bb.profile_events = []          # (start, end, n_active_log_index) per vocab GEMM
+  # live HIP-event timing of the two heaviest GEMM instantiations
+  bb.profile_events = {'gate_residual': [], 'vocab': []}
   t0 = time.perf_counter()
   for _ in range(args.steps):
     model.restore_model_and_sample(num_steps=args.T)
@@ -178,23 +180,41 @@ def main():
   bb.profile_events = None
   nfe_last = int(model.last_nfe.item())
 
-  # ---- roofline of the dominant kernel (vocab-projection GEMM) -------------
-  K = cfg.model.hidden_size
-  ms = [s.elapsed_time(e) for s, e, _ in events]
-  rows = [int(r) for _, _, r in events]  # live rows per launch (host copy of the device log)
-  n_launch = len(ms)
-  flops = sum(2.0 * r * V * K for r in rows)
-  t_gemm = sum(ms) * 1e-3
-  achieved = flops / t_gemm / 1e12 if t_gemm > 0 else 0.0
-  roofline = {
-    'kernel': 'gemm_bf16_kernel<EPI_STORE,bf16> (vocab projection, 768->50258)',
-    'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS,
-    'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4),
-    'traffic': None,
-    'launches': n_launch, 'avg_launch_ms': round(sum(ms) / max(1, n_launch), 4),
-    'avg_rows_per_launch': round(sum(rows) / max(1, n_launch), 1),
-    'algorithmic_flops_per_row': 2.0 * V * K,
-  }
+  # ---- roofline: algorithmic flops / launch time, from the live events ------
+  traffic = {}
+  tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+  if os.path.exists(tpath):   # HBM bytes per launch from separate rocprofv3 --pmc passes
+    traffic = json.load(open(tpath))
+
+  def roof(tag, kernel):
+    evs = events[tag]
+    ms = [s.elapsed_time(e) for s, e, _, _ in evs]
+    cache = {}
+    flops = 0.0
+    rows_sum = 0
+    for _, _, r, fpr in evs:
+      if torch.is_tensor(r):
+        k = r.data_ptr()
+        if k not in cache:
+          cache[k] = int(r)
+        r = cache[k]
+      flops += fpr * r
+      rows_sum += r
+    n = len(ms)
+    t = sum(ms) * 1e-3
+    ach = flops / t / 1e12 if t > 0 else 0.0
+    return {'kernel': kernel, 'bound': 'mfma', 'achieved': round(ach, 1),
+            'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(ach / PEAK_BF16_TFLOPS, 4),
+            'traffic': traffic.get(tag),
+            'launches': n, 'avg_launch_ms': round(sum(ms) / max(1, n), 4),
+            'avg_rows_per_launch': round(rows_sum / max(1, n), 1),
+            'algorithmic_gflop_per_launch': round(flops / max(1, n) / 1e9, 2)}
+  # dominant kernel by total time (profiles/r01_*_kernel_stats.csv): the
+  # gate/residual GEMM instantiation (out-projection K=768 and MLP-down K=3072)
+  roofline = roof('gate_residual',
+                  'gemm_bf16_kernel<EPI_GATE_RESIDUAL,fp32,256x256> (attn_out 768->768 and mlp.2 3072->768)')
+  roofline_vocab = roof('vocab', 'gemm_bf16_kernel<EPI_STORE,bf16,256x256> (vocab projection 768->50258, masked rows)')
 
   samples = world * B * args.steps
   value = samples / elapsed
@@ -212,9 +232,33 @@ def main():
     'nfe_per_sample': round(nfe_last / B, 1),
     'ms_per_denoise_step': round(elapsed / args.steps / (args.T + 1) * 1e3, 3),
     'roofline': roofline,
+    'roofline_vocab_gemm': roofline_vocab,
   }
   out['backbone_tflops'] = round(
     (nfe_last * 291.65e9 * args.steps) / elapsed / 1e12, 1)
+
+  if not args.no_eval:
+    # second half of the metric: NELBO eval tokens/s (q_xt + backbone + fused
+    # SUBS-NLL + fp64 sums; sequences sharded by rank, one all-reduce at the end)
+    eb = 32
+    g = torch.Generator(device='cuda').manual_seed(1 + rank)
+    ids = torch.randint(0, V - 1, (eb, L), generator=g, device='cuda')
+    ids[:, 0] = 50256; ids[:, -1] = 50256
+    batch = {'input_ids': ids, 'attention_mask': torch.ones(eb, L, device='cuda')}
+    model.on_validation_epoch_start()
+    model.validation_step(batch, 0)
+    sync_all()
+    model.valid_metrics.reset()
+    n_eval = 8
+    te = time.perf_counter()
+    for i in range(n_eval):
+      model.validation_step(batch, i)
+    res = model.valid_metrics.compute(sync_dist=True)
+    torch.cuda.synchronize()
+    te = mdist.max_over_ranks(time.perf_counter() - te, dev)
+    out['eval'] = {'metric': 'NELBO eval tokens/sec', 'value': round(world * n_eval * eb * L / te, 1),
+                   'unit': 'tokens/s', 'batch_per_gpu': eb, 'batches': n_eval,
+                   'val_nll': round(res['val/nll'], 4)}
 
   if rank == 0 and world == 1 and not args.no_policy_compare and args.cache_policy == 'sample':
     # the reference's literal all-or-nothing cache policy, for the record

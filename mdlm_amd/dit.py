@@ -212,6 +212,19 @@ class DIT(nn.Module):
     return self._conditioning(p, sigma), sigma.shape[0]
 
   # ------------------------------------------------------------------ forward
+  def _timed(self, tag, rows, flops_per_row, fn):
+    """bench.py hook: HIP events on the launch stream around one kernel launch
+    (`profile_events` is a dict tag -> list of (start, end, rows, flops/row))."""
+    ev = self.profile_events
+    if ev is None or tag not in ev:
+      return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    ev[tag].append((e0, e1, rows, flops_per_row))
+
   def run(self, indices, sigma, logits_out, sigma_is_zero=False, active=None,
           n_active_dev=None, n_rows_dev=None, n_max=None, row_map=None):
     """Run the backbone.  `indices` (B, L) int64.  `logits_out`: (B, L, V)
@@ -239,6 +252,10 @@ class DIT(nn.Module):
     q_ = qkv[:M * D]
     k_ = qkv[M * D:2 * M * D]
     vt_ = qkv[2 * M * D:3 * M * D]
+    ev = self.profile_events
+    rows_t = None
+    if ev is not None:  # one host copy of the live row count per forward
+      rows_t = n_rows_dev.clone() if n_rows_dev is not None else M
     for bp, mod in zip(p['blocks'], mods):
       # chunk order dit.py:249-250: shift_msa, scale_msa, gate_msa, shift_mlp,
       # scale_mlp, gate_mlp
@@ -248,42 +265,37 @@ class DIT(nn.Module):
                     rot_cos=p['cos'], rot_sin=p['sin'], n_heads=H,
                     m_rows_dev=n_rows_dev, ldc=0, M=M)
       ops.attn_fwd(q_, k_, vt_, ao, n_seq, H, L, n_seq_dev=n_active_dev)
-      ops.gemm_bf16(ao, bp['out'], x, EPI_GATE_RESIDUAL, gate=mod[:, 2 * D:3 * D],
-                    residual=x, rows_per_mod=L, n_mod=n_mod, mod_ld=ld6,
-                    m_rows_dev=n_rows_dev, M=M)
+      self._timed('gate_residual', rows_t, 2.0 * D * D, lambda: ops.gemm_bf16(
+        ao, bp['out'], x, EPI_GATE_RESIDUAL, gate=mod[:, 2 * D:3 * D],
+        residual=x, rows_per_mod=L, n_mod=n_mod, mod_ld=ld6,
+        m_rows_dev=n_rows_dev, M=M))
       ops.ln_modulate(x, bp['n2'], mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D], h,
                       L, n_mod, ld6, n_rows_dev)
       ops.gemm_bf16(h, bp['fc1'], mh, EPI_BIAS_GELU, bias=bp['b1'],
                     m_rows_dev=n_rows_dev, M=M)
-      ops.gemm_bf16(mh, bp['fc2'], x, EPI_GATE_RESIDUAL, bias=bp['b2'],
-                    gate=mod[:, 5 * D:6 * D], residual=x, rows_per_mod=L,
-                    n_mod=n_mod, mod_ld=ld6, m_rows_dev=n_rows_dev, M=M)
+      self._timed('gate_residual', rows_t, 2.0 * D * 4 * D, lambda: ops.gemm_bf16(
+        mh, bp['fc2'], x, EPI_GATE_RESIDUAL, bias=bp['b2'],
+        gate=mod[:, 5 * D:6 * D], residual=x, rows_per_mod=L,
+        n_mod=n_mod, mod_ld=ld6, m_rows_dev=n_rows_dev, M=M))
     fm = mods[-1]
     assert logits_out.shape[-1] == self.vocab_size
-    ev = getattr(self, 'profile_events', None)
+    V = self.vocab_size
     if row_map is not None:
       gather, scatter, live = row_map
       ops.ln_modulate(x, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod,
                       ld2, n_rows_dev=live, row_gather=gather, rows=M)
+      self._timed('vocab', live.clone() if ev is not None else None, 2.0 * V * D,
+                  lambda: ops.gemm_bf16(
+                    h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
+                    m_rows_dev=live, out_row_map=scatter,
+                    ldc=logits_out.stride(-2), M=M))
     else:
-      live = n_rows_dev
       ops.ln_modulate(x, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod,
                       ld2, n_rows_dev)
-    if ev is not None:  # bench.py: live HIP-event timing of the dominant kernel
-      e0 = torch.cuda.Event(enable_timing=True)
-      e1 = torch.cuda.Event(enable_timing=True)
-      e0.record()
-    if row_map is not None:
-      ops.gemm_bf16(h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
-                    m_rows_dev=live, out_row_map=scatter,
-                    ldc=logits_out.stride(-2), M=M)
-    else:
-      ops.gemm_bf16(h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
-                    rows_per_mod=L, m_rows_dev=n_rows_dev, out_sample_map=active,
-                    ldc=logits_out.stride(-2), M=M)
-    if ev is not None:
-      e1.record()
-      ev.append((e0, e1, live.clone() if live is not None else M))
+      self._timed('vocab', rows_t, 2.0 * V * D, lambda: ops.gemm_bf16(
+        h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
+        rows_per_mod=L, m_rows_dev=n_rows_dev, out_sample_map=active,
+        ldc=logits_out.stride(-2), M=M))
     return logits_out
 
   def forward(self, indices, sigma, out=None, out_dtype=torch.bfloat16):
