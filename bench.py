@@ -186,6 +186,12 @@ def main():
   if os.path.exists(tpath):   # HBM bytes per launch from separate rocprofv3 --pmc passes
     traffic = json.load(open(tpath))
 
+  def _traffic(tag, rows):
+    t = traffic.get(tag)
+    if not t:
+      return None
+    return round(t['hbm_bytes_per_launch'] / traffic.get('_rows_per_launch_profiled', 65536) * rows)
+
   def roof(tag, kernel):
     evs = events[tag]
     ms = [s.elapsed_time(e) for s, e, _, _ in evs]
@@ -206,7 +212,8 @@ def main():
     return {'kernel': kernel, 'bound': 'mfma', 'achieved': round(ach, 1),
             'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-            'traffic': traffic.get(tag),
+            'traffic': _traffic(tag, rows_sum / max(1, n)),
+            'traffic_unit': 'HBM bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json, scaled by rows)',
             'launches': n, 'avg_launch_ms': round(sum(ms) / max(1, n), 4),
             'avg_rows_per_launch': round(rows_sum / max(1, n), 1),
             'algorithmic_gflop_per_launch': round(flops / max(1, n) / 1e9, 2)}
