@@ -47,7 +47,7 @@ struct GemmArgs {
   const int32_t* m_rows_dev;
   int tiles_m, tiles_n, seq_len;
   int vec_ok;  // ldc / alignment allow 16-byte row stores
-  int dbg;     // timing experiments only (bit 1: skip the epilogue)
+  int dbg;     // timing experiments only (2: skip the epilogue, 4: drop the stores)
 };
 
 #define GLDS16(gptr, lptr) \
@@ -69,32 +69,46 @@ __device__ __forceinline__ float bf16_round(float x) { return bf16_to_f32(f32_to
 // are written once and read by a later kernel: non-temporal stores keep them
 // from displacing the A/W panels in L2 (measured -7..-14 % per launch); the
 // fp32 residual stream is read-modify-written in place and stays plain.
-// dbg bits are timing experiments only: 4 = drop the store, 8 = flip the
-// temporal hint.
+// dbg bit 4 (timing experiments only) drops the store.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ void store16(void* p, uint4 v, int dbg) {
   if (dbg & 4) return;
   const u32x4 vv = {v.x, v.y, v.z, v.w};
-  if (NT != ((dbg & 8) != 0)) __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(p));
+  if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(p));
   else *reinterpret_cast<u32x4*>(p) = vv;
 }
 
-// Epilogue of one 64x64 wave sub-tile.  SWAPPED accumulators (see header):
-// acc(m, n)[j] = C[grow0 + m*16 + fr][gcol0 + n*16 + fq*4 + j].
-// ep = this wave's 16 KiB LDS staging region.  rows_per_mod % 64 == 0 whenever
-// rows are decomposed into (sample, position), so a tile never straddles two
-// samples.
-template <int EPI, typename TC, int MT, int HALF>
-__device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char* ep,
-                                               int64_t grow0, int gcol0,
-                                               const GemmArgs& g, int lane) {
+// Per-lane column constants of one wave tile, fetched BEFORE the main loop so
+// their latency is hidden (interior wave tiles only; `ok` is wave-uniform).
+//   bf16 outputs: bias for columns gcol0 + n*16 + fq*4 + (0..3)   (register layout)
+//   fp32 outputs: bias / gate for columns gcol0 + (lane&15)*4 + (0..3)  (row layout)
+struct EpiConsts {
+  float4 bias4[4];
+  float4 b4, gt;
+  bool ok;       // interior wave tile with 16-byte row stores: vector path
+  bool gt_tile;  // gt holds the gate row of the whole wave tile (one sample)
+};
+
+// Epilogue of MS*16 rows x 64 columns of a wave tile (m sub-tiles M0..M0+MS-1).
+// SWAPPED accumulators (see header):
+//   acc(m, n)[j] = C[grow0 + m*16 + fr][gcol0 + n*16 + fq*4 + j].
+// ep = this wave's 8 KiB LDS region inside the stage buffer the main loop read
+// last (the other one already holds the next tile's first K slab):
+// [64 rows][64 bf16] or [32 rows][64 fp32].  rows_per_mod % 64 == 0 whenever
+// rows are decomposed into (sample, position), so a sub-tile never straddles
+// two samples.
+template <int EPI, typename TC, int MT, int M0, int MS>
+__device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* ep,
+                                             int64_t grow0, int gcol0, const EpiConsts& ec,
+                                             const GemmArgs& g, int lane) {
   const int fq = lane >> 4, fr = lane & 15;
   if (gcol0 >= g.N) return;  // wave tile entirely past the N edge (wave-uniform)
-#define acc(m, n) accf[HALF * 4 + (m)][n]
+#define acc(m, n) accf[M0 + (m)][n]
   constexpr bool BF16_OUT = sizeof(TC) == 2;
 
   if constexpr (EPI == MDLM_EPI_QKV_ROTARY) {
+    static_assert(MS == 4, "rotary epilogue works on 64-row sub-tiles");
     const int cg = gcol0 >> 6;               // (three, head) column group
     const int three = cg / g.n_heads;
     const int h = cg - three * g.n_heads;
@@ -120,23 +134,30 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
     // q / k: rotary in registers.  d = n*16 + fq*4 + j pairs with d + 32
     // (tiles n and n+2); Linear output is bf16 under autocast (dit.py:256,
     // 365); the rotary kernel reads bf16, rotates in fp32, writes bf16
-    // (dit.py:112-115, 264).
+    // (dit.py:112-115, 264).  All 16 table loads are issued first.
+    float4 cs[4][2], sn[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int64_t o = (pos0 + m * 16 + fr) * 32 + n * 16 + fq * 4;
+        cs[m][n] = *reinterpret_cast<const float4*>(g.rot_cos + o);
+        sn[m][n] = *reinterpret_cast<const float4*>(g.rot_sin + o);
+      }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int row = m * 16 + fr;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        const int d = n * 16 + fq * 4;
-        const float4 cs = *reinterpret_cast<const float4*>(g.rot_cos + (pos0 + row) * 32 + d);
-        const float4 sn = *reinterpret_cast<const float4*>(g.rot_sin + (pos0 + row) * 32 + d);
+        const float4 c4 = cs[m][n], s4 = sn[m][n];
         const float a0 = bf16_round(acc(m, n)[0]), a1 = bf16_round(acc(m, n)[1]);
         const float a2 = bf16_round(acc(m, n)[2]), a3 = bf16_round(acc(m, n)[3]);
         const float b0 = bf16_round(acc(m, n + 2)[0]), b1 = bf16_round(acc(m, n + 2)[1]);
         const float b2 = bf16_round(acc(m, n + 2)[2]), b3 = bf16_round(acc(m, n + 2)[3]);
-        const uint2 lo = make_uint2(pack_bf16x2(a0 * cs.x - b0 * sn.x, a1 * cs.y - b1 * sn.y),
-                                    pack_bf16x2(a2 * cs.z - b2 * sn.z, a3 * cs.w - b3 * sn.w));
-        const uint2 hi = make_uint2(pack_bf16x2(a0 * sn.x + b0 * cs.x, a1 * sn.y + b1 * cs.y),
-                                    pack_bf16x2(a2 * sn.z + b2 * cs.z, a3 * sn.w + b3 * cs.w));
+        const uint2 lo = make_uint2(pack_bf16x2(a0 * c4.x - b0 * s4.x, a1 * c4.y - b1 * s4.y),
+                                    pack_bf16x2(a2 * c4.z - b2 * s4.z, a3 * c4.w - b3 * s4.w));
+        const uint2 hi = make_uint2(pack_bf16x2(a0 * s4.x + b0 * c4.x, a1 * s4.y + b1 * c4.y),
+                                    pack_bf16x2(a2 * s4.z + b2 * c4.z, a3 * s4.w + b3 * c4.w));
         // bf16 tile [64][64], 16-B chunk index swizzled by (row & 7)
         const int c_lo = n * 2 + (fq >> 1), c_hi = c_lo + 4;
         *reinterpret_cast<uint2*>(ep + row * 128 + ((c_lo ^ (row & 7)) * 16) + (fq & 1) * 8) = lo;
@@ -152,22 +173,7 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
     }
     return;
   } else {
-    // per-lane column constants: columns gcol0 + n*16 + fq*4 + (0..3)
-    float4 bias4[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int gc = gcol0 + n * 16 + fq * 4;
-      bias4[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g.bias) {
-        if (gc + 3 < g.N) bias4[n] = *reinterpret_cast<const float4*>(g.bias + gc);
-        else {
-          if (gc < g.N) bias4[n].x = g.bias[gc];
-          if (gc + 1 < g.N) bias4[n].y = g.bias[gc + 1];
-          if (gc + 2 < g.N) bias4[n].z = g.bias[gc + 2];
-        }
-      }
-    }
-    // output row of tile row 0 (scatter of compacted samples, STORE only)
+    // output row of sub-tile row 0 (scatter of compacted samples, STORE only)
     int64_t orow0 = grow0;
     if constexpr (EPI == MDLM_EPI_STORE) {
       if (g.out_sample_map) {
@@ -177,29 +183,28 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
     }
     const float* gate_row = nullptr;
     if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL) {
-      // gate row is constant over the tile (rows_per_mod % 64 == 0)
+      // gate row is constant over the sub-tile (rows_per_mod % 64 == 0)
       const int64_t mrow = g.n_mod == 1 ? 0 : (grow0 / g.rows_per_mod) % g.n_mod;
       gate_row = g.gate + mrow * g.mod_ld;
     }
     TC* const Cp0 = reinterpret_cast<TC*>(g.C) + gcol0;
-    // destination row of tile row `row` (per-row scatter list: STORE only; -1 = skip)
+    // destination row of sub-tile row `row` (per-row scatter list: STORE only; -1 = skip)
     auto dst_row = [&](int row) -> int64_t {
       if constexpr (EPI == MDLM_EPI_STORE) {
         if (g.out_row_map) return (int64_t)g.out_row_map[grow0 + row];
       }
       return orow0 + row;
     };
-    const bool fast = g.vec_ok && (gcol0 + 63 < g.N);  // wave-uniform
-    if (fast) {
+    if (ec.ok) {
       if constexpr (BF16_OUT) {
-        // registers -> (bias, GELU) -> packed bf16 -> swizzled LDS tile [64][64]
+        // registers -> (bias, GELU) -> packed bf16 -> swizzled LDS tile [MS*16][64]
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MS; ++m) {
           const int row = m * 16 + fr;
 #pragma unroll
           for (int n = 0; n < 4; ++n) {
-            float v0 = acc(m, n)[0] + bias4[n].x, v1 = acc(m, n)[1] + bias4[n].y;
-            float v2 = acc(m, n)[2] + bias4[n].z, v3 = acc(m, n)[3] + bias4[n].w;
+            float v0 = acc(m, n)[0] + ec.bias4[n].x, v1 = acc(m, n)[1] + ec.bias4[n].y;
+            float v2 = acc(m, n)[2] + ec.bias4[n].z, v3 = acc(m, n)[3] + ec.bias4[n].w;
             if constexpr (EPI == MDLM_EPI_BIAS_GELU) {
               v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
             }
@@ -209,16 +214,27 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
           }
         }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < MS * 2; ++it) {
           const int row = it * 8 + (lane >> 3), ch = lane & 7;
           const uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((ch ^ (row & 7)) * 16));
           const int64_t dr = dst_row(row);
           if (dr >= 0) store16<true>(Cp0 + dr * g.ldc + ch * 8, v, g.dbg);
         }
       } else {
-        // fp32 tile [64][64], 16-B chunk index swizzled by (row & 15)
+        // fp32 tile [MS*16][64], 16-B chunk index swizzled by (row & 15).
+        const int ch = lane & 15;
+        const int gc = gcol0 + ch * 4;
+        // The residual rows are fetched with all loads in flight, not one
+        // load -> wait -> store per row.
+        float4 rs[MS * 4];
+        if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL) {
+          const float* rp = g.residual + (grow0 + (lane >> 4)) * g.ldc + gc;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+          for (int it = 0; it < MS * 4; ++it)
+            rs[it] = *reinterpret_cast<const float4*>(rp + (int64_t)(it * 4) * g.ldc);
+        }
+#pragma unroll
+        for (int m = 0; m < MS; ++m) {
           const int row = m * 16 + fr;
 #pragma unroll
           for (int n = 0; n < 4; ++n) {
@@ -226,21 +242,20 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
             *reinterpret_cast<f32x4*>(ep + row * 256 + ((c16 ^ (row & 15)) * 16)) = acc(m, n);
           }
         }
-        const int ch = lane & 15;
-        const int gc = gcol0 + ch * 4;
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), gt = b4;
-        if (g.bias) b4 = *reinterpret_cast<const float4*>(g.bias + gc);
-        if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL) gt = *reinterpret_cast<const float4*>(gate_row + gc);
+        const float4 b4 = ec.b4;
+        float4 gt = ec.gt;
+        if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL) {
+          if (!ec.gt_tile) gt = *reinterpret_cast<const float4*>(gate_row + gc);
+        }
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
+        for (int it = 0; it < MS * 4; ++it) {
           const int row = it * 4 + (lane >> 4);
           float4 v = *reinterpret_cast<const float4*>(ep + row * 256 + ((ch ^ (row & 15)) * 16));
           v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
           if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL) {
             // residual + gate * x (bias_dropout_add_scale, eval), dit.py:28-34
-            const float4 rs = *reinterpret_cast<const float4*>(g.residual + (grow0 + row) * g.ldc + gc);
-            v.x = rs.x + gt.x * v.x; v.y = rs.y + gt.y * v.y;
-            v.z = rs.z + gt.z * v.z; v.w = rs.w + gt.w * v.w;
+            v.x = rs[it].x + gt.x * v.x; v.y = rs[it].y + gt.y * v.y;
+            v.z = rs[it].z + gt.z * v.z; v.w = rs[it].w + gt.w * v.w;
           }
           const int64_t dr = dst_row(row);
           if (dr >= 0) store16<false>(Cp0 + dr * g.ldc + ch * 4, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), g.dbg);
@@ -249,18 +264,17 @@ __device__ __forceinline__ void epilogue_64x64(const f32x4 (&accf)[MT][4], char*
     } else {
       // N edge / unaligned ldc: element-wise masked stores straight from registers
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < MS; ++m) {
         const int row = m * 16 + fr;
         const int64_t dr = dst_row(row);
         if (dr < 0) continue;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-          const float bb[4] = {bias4[n].x, bias4[n].y, bias4[n].z, bias4[n].w};
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
             const int cc = n * 16 + fq * 4 + jj;
             if (gcol0 + cc < g.N) {
-              float o = acc(m, n)[jj] + bb[jj];
+              float o = acc(m, n)[jj] + (g.bias ? g.bias[gcol0 + cc] : 0.f);
               if constexpr (EPI == MDLM_EPI_BIAS_GELU) o = gelu_tanh(o);
               if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL)
                 o = g.residual[(grow0 + row) * g.ldc + gcol0 + cc] + gate_row[gcol0 + cc] * o;
@@ -281,8 +295,11 @@ void gemm_bf16_kernel(GemmArgs g) {
   constexpr int NW = WM * WN;
   constexpr int TBM = WM * MT * 16, TBN = WN * 64;
   constexpr int A_BYTES = TBM * BK * 2, B_BYTES = TBN * BK * 2;
+  constexpr int STAGE = A_BYTES + B_BYTES;   // one K slab of A and W; two stages
   constexpr int A_CH = (TBM / 8) / NW, B_CH = (TBN / 8) / NW;  // 1 KiB chunks per wave
   constexpr int GROUP_M = 1024 / TBM;  // 1024 rows of A (1.5 MiB at K=768) per group
+  constexpr bool BF16_OUT = sizeof(TC) == 2;
+  static_assert(STAGE / NW == 8192, "epilogue regions are 8 KiB per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -292,29 +309,25 @@ void gemm_bf16_kernel(GemmArgs g) {
   // Workgroup b belongs to XCD group b & 7 and walks that group's tile
   // sequence (groups of 1024 A rows x all N tiles, N outer) with stride
   // gridDim/8: the workgroups resident on one XCD work on neighbouring tiles
-  // (shared A panels in its L2).  With grid = 8 * seq_len every workgroup
-  // owns one tile; with a CU-sized grid the kernel is persistent and the
-  // stores of tile i drain under the main loop of tile i+1.
+  // (shared A panels in its L2).  The K slabs of consecutive tiles form ONE
+  // double-buffered stream: the last K step of tile i prefetches the first
+  // slab of tile i+1, whose load latency and the stores of tile i then overlap.
   const int bid = blockIdx.x;
   const int xcd = bid & 7;
   const int slots = gridDim.x >> 3;
   const int per_group = GROUP_M * g.tiles_n;
-  bool first_tile = true;
-  for (int j = bid >> 3; j < g.seq_len; j += slots) {
-  const int gl = j / per_group;
-  const int rem = j - gl * per_group;
-  const int tn = rem / GROUP_M;
-  const int mi = rem - tn * GROUP_M;
-  const int tm = (gl * 8 + xcd) * GROUP_M + mi;
-  if (tm >= g.tiles_m) continue;
-  const int64_t m0 = (int64_t)tm * TBM;
-  if (g.m_rows_dev && m0 >= (int64_t)*g.m_rows_dev) continue;
-  const int n0 = tn * TBN;
-  // the previous tile's epilogue staged through LDS regions this tile's DMA
-  // overwrites: every wave must be done reading them
-  if (!first_tile) __syncthreads();
-  first_tile = false;
-
+  const int64_t m_lim = g.m_rows_dev ? (int64_t)*g.m_rows_dev : g.M;
+  // next valid tile at or after sequence index j (-1: none)
+  auto next_tile = [&](int j, int& tm, int& tn) -> int {
+    for (; j < g.seq_len; j += slots) {
+      const int gl = j / per_group;
+      const int rem = j - gl * per_group;
+      tn = rem / GROUP_M;
+      tm = (gl * 8 + xcd) * GROUP_M + (rem - tn * GROUP_M);
+      if (tm < g.tiles_m && (int64_t)tm * TBM < m_lim) return j;
+    }
+    return -1;
+  };
 
   // ---- staging addresses -------------------------------------------------
   // chunk c = i*NW + wid covers tile rows c*8 .. c*8+7; lane -> (row lane>>3,
@@ -323,25 +336,27 @@ void gemm_bf16_kernel(GemmArgs g) {
   const int skc = ((lane & 7) ^ srow) * 8;  // element offset inside the 64-wide K slab
   const bf16_t* a_src[A_CH];
   const bf16_t* b_src[B_CH];
-#pragma unroll
-  for (int i = 0; i < A_CH; ++i)
-    a_src[i] = g.A + (m0 + (i * NW + wid) * 8 + srow) * g.lda + skc;
-#pragma unroll
-  for (int i = 0; i < B_CH; ++i) {
-    int brow = n0 + (i * NW + wid) * 8 + srow;
-    brow = brow < g.N ? brow : g.N - 1;  // clamp the N edge (stores are masked)
-    b_src[i] = g.W + (int64_t)brow * g.K + skc;
-  }
-  char* const ldsA = smem;                 // 2 x A_BYTES
-  char* const ldsB = smem + 2 * A_BYTES;   // 2 x B_BYTES
-
-  auto stage = [&](int buf, int k0) {
+  auto set_src = [&](int tm, int tn) {
+    const int64_t m0 = (int64_t)tm * TBM;
+    const int n0 = tn * TBN;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
-      GLDS16(a_src[i] + k0, ldsA + buf * A_BYTES + (i * NW + wid) * 1024);
+      a_src[i] = g.A + (m0 + (i * NW + wid) * 8 + srow) * g.lda + skc;
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      int brow = n0 + (i * NW + wid) * 8 + srow;
+      brow = brow < g.N ? brow : g.N - 1;  // clamp the N edge (stores are masked)
+      b_src[i] = g.W + (int64_t)brow * g.K + skc;
+    }
+  };
+  auto stage = [&](int buf, int k0) {
+    char* const sb = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      GLDS16(a_src[i] + k0, sb + (i * NW + wid) * 1024);
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
-      GLDS16(b_src[i] + k0, ldsB + buf * B_BYTES + (i * NW + wid) * 1024);
+      GLDS16(b_src[i] + k0, sb + A_BYTES + (i * NW + wid) * 1024);
   };
 
   // ---- fragment read offsets ---------------------------------------------
@@ -352,65 +367,132 @@ void gemm_bf16_kernel(GemmArgs g) {
   for (int ks = 0; ks < 2; ++ks)
     foff[ks] = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) * 16);
   const int a_base = wr * (MT * 16) * 128;
-  const int b_base = wc * 64 * 128;
-
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // natural operand order only for the V slice of the QKV GEMM (wave-uniform)
-  bool natural = false;
-  if constexpr (EPI == MDLM_EPI_QKV_ROTARY)
-    natural = ((n0 + wc * 64) >> 6) / g.n_heads == 2;
-
+  const int b_base = A_BYTES + wc * 64 * 128;
   const int KT = g.K / BK;
-  auto mainloop = [&](auto nat) {
-    constexpr bool NAT = decltype(nat)::value;
-    stage(0, 0);
-    __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) before the barrier
-    for (int kt = 0; kt < KT; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < KT) stage(cur ^ 1, (kt + 1) * BK);
-      const char* At = ldsA + cur * A_BYTES + a_base;
-      const char* Bt = ldsB + cur * B_BYTES + b_base;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[MT], bfr[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-          bfr[n] = *reinterpret_cast<const bf16x8*>(Bt + n * 2048 + foff[ks]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          af[m] = *reinterpret_cast<const bf16x8*>(At + m * 2048 + foff[ks]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int n = 0; n < 4; ++n) {
-            if constexpr (NAT)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
-            else
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[n], af[m], acc[m][n], 0, 0, 0);
-          }
-      }
-      __syncthreads();
-    }
-  };
-  if constexpr (EPI == MDLM_EPI_QKV_ROTARY) {
-    if (natural) mainloop(std::true_type{}); else mainloop(std::false_type{});
-  } else {
-    mainloop(std::false_type{});
-  }
 
-  // ---- epilogue: MT/4 passes of a 64x64 sub-tile through this wave's LDS ----
-  if (g.dbg & 2) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(g.C)[0] = 1.f; continue; }
-  char* ep = smem + wid * 16384;
-  const int gcol0 = n0 + wc * 64;
-  const int64_t growW = m0 + wr * (MT * 16);
-  epilogue_64x64<EPI, TC, MT, 0>(acc, ep, growW, gcol0, g, lane);
-  if constexpr (MT == 8) epilogue_64x64<EPI, TC, MT, 1>(acc, ep, growW + 64, gcol0, g, lane);
-  }  // tile loop
+  int tm, tn;
+  int j = next_tile(bid >> 3, tm, tn);
+  if (j < 0) return;
+  set_src(tm, tn);
+  stage(0, 0);
+  int buf = 0;          // stage holding the slab the next K step reads
+  __syncthreads();      // hipcc drains the LDS-DMA (vmcnt(0)) before the barrier
+
+  while (true) {
+    int tm_next, tn_next;
+    const int j_next = next_tile(j + slots, tm_next, tn_next);
+    const int64_t m0 = (int64_t)tm * TBM;
+    const int n0 = tn * TBN;
+    const int gcol0 = n0 + wc * 64;
+
+    // ---- column constants of this wave tile (latency hidden by the K loop) --
+    EpiConsts ec;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    ec.ok = g.vec_ok && (gcol0 + 63 < g.N);  // wave-uniform
+    ec.gt_tile = false;
+    ec.b4 = zero4; ec.gt = zero4;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) ec.bias4[n] = zero4;
+    if constexpr (EPI != MDLM_EPI_QKV_ROTARY) {
+      if (ec.ok) {
+        if constexpr (BF16_OUT) {
+          if (g.bias) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+              ec.bias4[n] = *reinterpret_cast<const float4*>(g.bias + gcol0 + n * 16 + (lane >> 4) * 4);
+          }
+        } else {
+          const int gc = gcol0 + (lane & 15) * 4;
+          if (g.bias) ec.b4 = *reinterpret_cast<const float4*>(g.bias + gc);
+          if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL) {
+            // one gate row for the whole wave tile unless samples are shorter than it
+            ec.gt_tile = g.n_mod == 1 || g.rows_per_mod % (MT * 16) == 0;
+            if (ec.gt_tile) {
+              const int64_t growW = m0 + wr * (MT * 16);
+              const int64_t mrow = g.n_mod == 1 ? 0 : (growW / g.rows_per_mod) % g.n_mod;
+              ec.gt = *reinterpret_cast<const float4*>(g.gate + mrow * g.mod_ld + gc);
+            }
+          }
+        }
+      }
+    }
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // natural operand order only for the V slice of the QKV GEMM (wave-uniform)
+    bool natural = false;
+    if constexpr (EPI == MDLM_EPI_QKV_ROTARY)
+      natural = (gcol0 >> 6) / g.n_heads == 2;
+
+    auto mainloop = [&](auto nat) {
+      constexpr bool NAT = decltype(nat)::value;
+      for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) {
+          stage(buf ^ 1, (kt + 1) * BK);
+        } else if (j_next >= 0) {
+          set_src(tm_next, tn_next);   // first slab of the next tile
+          stage(buf ^ 1, 0);
+        }
+        const char* At = smem + buf * STAGE + a_base;
+        const char* Bt = smem + buf * STAGE + b_base;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 af[MT], bfr[4];
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            bfr[n] = *reinterpret_cast<const bf16x8*>(Bt + n * 2048 + foff[ks]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            af[m] = *reinterpret_cast<const bf16x8*>(At + m * 2048 + foff[ks]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+              if constexpr (NAT)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+              else
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[n], af[m], acc[m][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+      }
+    };
+    if constexpr (EPI == MDLM_EPI_QKV_ROTARY) {
+      if (natural) mainloop(std::true_type{}); else mainloop(std::false_type{});
+    } else {
+      mainloop(std::false_type{});
+    }
+
+    // ---- epilogue through this wave's 8 KiB of the stage read last ----------
+    // (dbg bit 2, timing experiments only: skip it)
+    if (!(g.dbg & 2)) {
+      char* ep = smem + (buf ^ 1) * STAGE + wid * 8192;
+      const int64_t growW = m0 + wr * (MT * 16);
+      if constexpr (BF16_OUT) {
+        epilogue_sub<EPI, TC, MT, 0, 4>(acc, ep, growW, gcol0, ec, g, lane);
+        if constexpr (MT == 8) epilogue_sub<EPI, TC, MT, 4, 4>(acc, ep, growW + 64, gcol0, ec, g, lane);
+      } else {
+        epilogue_sub<EPI, TC, MT, 0, 2>(acc, ep, growW, gcol0, ec, g, lane);
+        epilogue_sub<EPI, TC, MT, 2, 2>(acc, ep, growW + 32, gcol0, ec, g, lane);
+        if constexpr (MT == 8) {
+          epilogue_sub<EPI, TC, MT, 4, 2>(acc, ep, growW + 64, gcol0, ec, g, lane);
+          epilogue_sub<EPI, TC, MT, 6, 2>(acc, ep, growW + 96, gcol0, ec, g, lane);
+        }
+      }
+    } else if (acc[0][0][0] == 123.456f) {
+      reinterpret_cast<float*>(g.C)[0] = 1.f;
+    }
+    if (j_next < 0) break;
+    j = j_next; tm = tm_next; tn = tn_next;
+    // every wave must be done with its epilogue region before the next K
+    // step's DMA overwrites that stage
+    __syncthreads();
+  }
 }
 
 template <int EPI, typename TC, int WM, int WN, int MT>
@@ -434,9 +516,9 @@ static int launch_cfg(GemmArgs g, hipStream_t s) {
   int64_t grid = (int64_t)8 * g.seq_len;
   if (grid >= (1ll << 31)) { set_error("gemm: grid too large"); return -1; }
   // persistent launch: one workgroup per CU for the 128 KiB-LDS tile, two for
-  // the 64 KiB one (dbg bit 6 = 64 restores one tile per workgroup)
+  // the 64 KiB one
   const int64_t resident = (LDS > 80 * 1024) ? 256 : 512;
-  if (!(g.dbg & 64) && grid > resident) grid = resident;
+  if (grid > resident) grid = resident;
   gemm_bf16_kernel<EPI, TC, WM, WN, MT><<<(unsigned)grid, 64 * WM * WN, LDS, s>>>(g);
   MDLM_LAUNCH_CHECK();
   return 0;

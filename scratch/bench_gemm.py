@@ -35,6 +35,33 @@ def run(M, mode):
   res['mlp2'] = (bench(lambda: ops.gemm_bf16(mh, W2, x, EPI_GATE_RESIDUAL, bias=b2, gate=mod[:, :D], residual=x, rows_per_mod=L, n_mod=1, mod_ld=6 * D)), 2 * M * 4 * D * D)
   res['vocab'] = (bench(lambda: ops.gemm_bf16(h, Wv, logits, EPI_STORE, bias=bv, rows_per_mod=L, ldc=logits.stride(-2)), iters=5), 2 * M * V * D)
   print(f'M={M} mode={mode}: ' + '  '.join(f'{k} {t*1e3:7.1f}us {f/t/1e9:6.0f}TF' for k, (t, f) in res.items()))
+import sys as _s
+modes = [int(a) for a in _s.argv[1:]] or [0, 16]
+def check(M=4096):
+  D = 768; V = 50258
+  h = torch.randn(M, D, device='cuda').bfloat16(); mh = torch.randn(M, 4 * D, device='cuda').bfloat16()
+  x0 = torch.randn(M, D, device='cuda')
+  Wqkv = (torch.randn(3 * D, D, device='cuda') * 0.04).bfloat16()
+  W2 = (torch.randn(D, 4 * D, device='cuda') * 0.02).bfloat16(); b2 = torch.randn(D, device='cuda') * 0.02
+  W1 = (torch.randn(4 * D, D, device='cuda') * 0.02).bfloat16(); b1 = torch.randn(4 * D, device='cuda') * 0.02
+  Wv = (torch.randn(V, D, device='cuda') * 0.08).bfloat16(); bv = torch.randn(V, device='cuda') * 0.02
+  mod = torch.randn(M // L, 6 * D, device='cuda')
+  cos = torch.randn(L, 32, device='cuda'); sin = torch.randn(L, 32, device='cuda')
+  outs = {}
+  for mode in modes:
+    ops.gemm_set_tile(mode)
+    qkv = torch.zeros(3 * M * D, device='cuda', dtype=torch.bfloat16)
+    ops.gemm_bf16(h, Wqkv, qkv, EPI_QKV_ROTARY, rows_per_mod=L, rot_cos=cos, rot_sin=sin, n_heads=12, ldc=0)
+    x = x0.clone()
+    ops.gemm_bf16(mh, W2, x, EPI_GATE_RESIDUAL, bias=b2, gate=mod[:, :D], residual=x, rows_per_mod=L, n_mod=M // L, mod_ld=6 * D)
+    m1 = torch.zeros(M, 4 * D, device='cuda', dtype=torch.bfloat16)
+    ops.gemm_bf16(h, W1, m1, EPI_BIAS_GELU, bias=b1)
+    lg = ops.alloc_logits(M // L, L, V); lg.zero_()
+    ops.gemm_bf16(h, Wv, lg, EPI_STORE, bias=bv, rows_per_mod=L, ldc=lg.stride(-2))
+    outs[mode] = (qkv, x, m1, lg)
+  a, b = outs[modes[0]], outs[modes[-1]]
+  print('check maxdiff:', [float((p.float() - q.float()).abs().max()) for p, q in zip(a, b)])
+check()
 for M in (65536,):
-  for mode in (0, 0, 2, 4, 8):
+  for mode in modes:
     run(M, mode)
