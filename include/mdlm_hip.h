@@ -94,6 +94,42 @@ int mdlm_subs_ddpm_update(const void* logits, int64_t ld, int dtype,
                           int B, int L, int V, int mask_index, int fast_math,
                           void* stream);
 
+/* Generic masked-row categorical race from cached LOGITS, for the other two
+ * samplers of the reference.  A masked position draws
+ *   argmax_v q_v / g_v,  q_v = exp(logit_v - lse) * q_scale[b] (v != mask),
+ *                         q_mask = q_mask[b];
+ * unmasked positions keep their token.  q_scale, q_mask: (B) fp32, computed by
+ * the caller from the noise schedule:
+ *   Diffusion._ddpm_update      (diffusion.py:612-637): q_scale = mc_t - mc_s,
+ *                                q_mask = mc_s  (mc = 1 - exp(-sigma));
+ *   Diffusion._analytic_update  (diffusion.py:773-780 with get_score 721-764,
+ *     _staggered_score 766-771, _transp_transition 791-798), in closed form for
+ *     SUBS outputs: q_scale = k e^{ds} (1 - e^{-ds}), q_mask = e^{ds} +
+ *     (1 - e^{ds})(k + 1), k = 1/expm1(sigma); an unmasked position has a
+ *     single non-zero probability (its own token);
+ *   Diffusion._denoiser_update  (diffusion.py:782-789): same with ds = sigma
+ *     and q_mask = 0.
+ * Other arguments as mdlm_subs_ddpm_update. */
+int mdlm_subs_race_update(const void* logits, int64_t ld, int dtype,
+                          float* lse, const int32_t* fresh,
+                          const int64_t* x, const float* q_scale,
+                          const float* q_mask, const float* u, uint64_t seed,
+                          uint64_t offset, int64_t* x_next, int32_t* changed,
+                          int B, int L, int V, int mask_index, int fast_math,
+                          void* stream);
+
+/* Discrete-time (T > 0) SUBS loss term, Diffusion._d3pm_loss,
+ * diffusion.py:329-358, given neg_logp_x0 (B, L) = -log p_theta(x0 | xt) (the
+ * output of mdlm_subs_nll with weight 1, no attention mask), xt (B, L), the
+ * discretised t (B) of diffusion.py:849-853 and T; attn_mask (B, L) fp32 or
+ * NULL multiplies the result (diffusion.py:908).  out (B, L) fp32.  The mask
+ * column of a SUBS output has probability exactly 0, so no second gather is
+ * needed; samples with t == 1/T yield NaN exactly as the reference does
+ * (0/0 at line 350). */
+int mdlm_d3pm_loss(const float* neg_logp_x0, const int64_t* xt, const float* t,
+                   int T, const float* attn_mask, float* out, int B, int L,
+                   int mask_index, void* stream);
+
 /* The uniforms the in-kernel generator uses, materialised (rows, V) fp32, so
  * that tests can feed the oracle the same draw.  Test/diagnostic helper; no
  * reference counterpart (the reference calls torch.rand_like, diffusion.py:27). */

@@ -285,6 +285,7 @@ __global__ __launch_bounds__(NT) void ddpm_update_kernel(
     const T* __restrict__ src, int64_t ld, float* __restrict__ lse_arr,
     const int32_t* __restrict__ fresh,
     const int64_t* __restrict__ x, const float* __restrict__ t, float dt,
+    const float* __restrict__ q_scale, const float* __restrict__ q_mask,
     const float* __restrict__ u, uint64_t seed, uint64_t offset,
     int64_t* __restrict__ x_next, int32_t* __restrict__ changed, int L, int V,
     int mask) {
@@ -297,9 +298,14 @@ __global__ __launch_bounds__(NT) void ddpm_update_kernel(
     return;
   }
   const int b = (int)(r / L);
-  const float mt = t[b];
-  const float ms = mt - dt;          // diffusion.py:599 (fp32)
-  const float factor = mt - ms;      // diffusion.py:605 (not fp32(dt))
+  float ms, factor;
+  if (q_scale) {   // generic race: q_v = p_v * q_scale[b], q_mask = q_mask[b]
+    factor = q_scale[b]; ms = q_mask[b];
+  } else {
+    const float mt = t[b];
+    ms = mt - dt;          // diffusion.py:599 (fp32)
+    factor = mt - ms;      // diffusion.py:605 (not fp32(dt))
+  }
   const T* row = src + r * ld;
   float lse = 0.f;
   if constexpr (SRC == 1) {
@@ -399,6 +405,7 @@ __global__ __launch_bounds__(NT) void ddpm_update_fast_kernel(
     const T* __restrict__ src, int64_t ld, float* __restrict__ lse_arr,
     const int32_t* __restrict__ fresh,
     const int64_t* __restrict__ x, const float* __restrict__ t, float dt,
+    const float* __restrict__ q_scale, const float* __restrict__ q_mask,
     uint64_t seed, uint64_t offset, int64_t* __restrict__ x_next,
     int32_t* __restrict__ changed, int L, int V, int mask) {
   __shared__ float smv[4]; __shared__ int smi[4];
@@ -410,9 +417,14 @@ __global__ __launch_bounds__(NT) void ddpm_update_fast_kernel(
     return;
   }
   const int b = (int)(r / L);
-  const float mt = t[b];
-  const float ms = mt - dt;          // diffusion.py:599 (fp32)
-  const float factor = mt - ms;      // diffusion.py:605
+  float ms, factor;
+  if (q_scale) {   // generic race: q_v = p_v * q_scale[b], q_mask = q_mask[b]
+    factor = q_scale[b]; ms = q_mask[b];
+  } else {
+    const float mt = t[b];
+    ms = mt - dt;          // diffusion.py:599 (fp32)
+    factor = mt - ms;      // diffusion.py:605
+  }
   const T* row = src + r * ld;
   const uint64_t G = (uint64_t)((V + 3) >> 2);
   const uint64_t ctr0 = offset + (uint64_t)r * G;
@@ -490,6 +502,35 @@ __global__ __launch_bounds__(NT) void ddpm_update_fast_kernel(
     x_next[r] = best;
     if (best != mask && changed) changed[b] = 1;  // benign race: all write 1
   }
+}
+
+// Discrete-time SUBS loss term, diffusion.py:329-358.  For SUBS outputs the
+// mask-column probability exp(model_output[..., mask]) is exactly 0 (the column
+// holds -1e6 - lse or -1e6), so only log p(x0) is needed; every other factor is
+// restated literally, including the 0/0 = NaN the reference produces for the
+// samples with t == 1/T (t - dt == 0).
+__global__ void d3pm_loss_kernel(const float* __restrict__ neg_logp_x0,
+                                 const int64_t* __restrict__ xt,
+                                 const float* __restrict__ t, int T,
+                                 const float* __restrict__ attn_mask,
+                                 float* __restrict__ out, int64_t n, int L, int mask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = (int)(i / L);
+  const float dt = (float)(1.0 / (double)T);                          // 330
+  const float tt = fminf(fmaxf(t[b], 0.f), (float)(1. - 1e-4));       // 335
+  const float alpha_t = 1.f - tt;                                      // 336
+  const float alpha_s = 1.f - (tt - dt);                               // 337
+  const float x_m = 0.f;                                               // 341-342
+  const float lp = -neg_logp_x0[i];                                    // 339-340
+  const float c1 = dt / tt;                                            // 344
+  const float nr = logf(__fadd_rn(__fdiv_rn(__fmul_rn(alpha_t, x_m), tt), 1.f));        // 345
+  const float c2 = 1.f - dt / tt;                                      // 348
+  const float dr2 = logf(__fadd_rn(__fdiv_rn(__fmul_rn(alpha_s, x_m), tt - dt), 1.f));  // 350
+  const float lvb = __fadd_rn(__fmul_rn(c1, nr - lp), __fmul_rn(c2, nr - dr2));         // 352-354
+  float o = (float)T * __fmul_rn(lvb, xt[i] == mask ? 1.f : 0.f);     // 356-358
+  if (attn_mask) o = __fmul_rn(o, attn_mask[i]);                       // 908
+  out[i] = o;
 }
 
 __global__ void philox_uniform_kernel(float* out, int64_t rows, int V,
@@ -605,31 +646,43 @@ __global__ __launch_bounds__(1024) void masked_row_map_kernel(
     const int32_t* __restrict__ n_active, int L, int mask, int pad,
     int32_t* __restrict__ gather, int32_t* __restrict__ scatter,
     int32_t* __restrict__ n_out) {
+  // one workgroup; every thread owns RPT consecutive rows per sweep, so a
+  // sweep covers 8192 rows with one wave scan + one cross-wave scan
+  constexpr int RPT = 8;
   __shared__ int wsum[16];
   __shared__ int base_s;
   const int n_rows = *n_active * L;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x == 0) base_s = 0;
   __syncthreads();
-  for (int r0 = 0; r0 < n_rows; r0 += 1024) {
-    const int r = r0 + threadIdx.x;
-    int dst = -1;
-    bool on = false;
-    if (r < n_rows) {
-      const int i = r / L, pos = r - i * L;
-      dst = active[i] * L + pos;
-      on = x[dst] == mask;
+  for (int r0 = 0; r0 < n_rows; r0 += 1024 * RPT) {
+    const int rbeg = r0 + threadIdx.x * RPT;
+    int dst[RPT];
+    unsigned on = 0;
+#pragma unroll
+    for (int c = 0; c < RPT; ++c) {
+      const int r = rbeg + c;
+      dst[c] = -1;
+      if (r < n_rows) {
+        const int i = r / L, pos = r - i * L;
+        dst[c] = active[i] * L + pos;
+        if (x[dst[c]] == mask) on |= 1u << c;
+      }
     }
-    const unsigned long long m = __ballot(on);
-    if (lane == 0) wsum[w] = __popcll(m);
+    const int cnt = __popc(on);
+    int incl = cnt;   // inclusive wave scan of the per-thread counts
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[w] = incl;
     __syncthreads();
-    int off = base_s;
+    int off = base_s + incl - cnt;
     for (int k = 0; k < w; ++k) off += wsum[k];
-    if (on) {
-      const int k = off + __popcll(m & ((1ull << lane) - 1ull));
-      gather[k] = r;
-      scatter[k] = dst;
-    }
+#pragma unroll
+    for (int c = 0; c < RPT; ++c)
+      if (on & (1u << c)) { gather[off] = rbeg + c; scatter[off] = dst[c]; ++off; }
     __syncthreads();
     if (threadIdx.x == 0) {
       int t = 0;
@@ -721,11 +774,13 @@ template <int SRC>
 static int launch_update(const void* src, int64_t ld, int dtype, float* lse,
                          const int32_t* fresh,
                          const int64_t* x, const float* t, double dt,
+                         const float* q_scale, const float* q_mask,
                          const float* u, uint64_t seed, uint64_t offset,
                          int64_t* x_next, int32_t* changed, int B, int L, int V,
                          int mask_index, int fast_math, void* stream) {
-  const char* nm = SRC ? "subs_ddpm_update" : "ddpm_cache_update";
-  MDLM_CHECK_ARG(src && x && t && x_next, "%s: null pointer", nm);
+  const char* nm = q_scale ? "subs_race_update" : SRC ? "subs_ddpm_update" : "ddpm_cache_update";
+  MDLM_CHECK_ARG(src && x && (t || q_scale) && x_next, "%s: null pointer", nm);
+  MDLM_CHECK_ARG(!q_scale == !q_mask, "%s: q_scale and q_mask go together", nm);
   MDLM_CHECK_ARG(SRC == 0 || lse, "%s: lse is required", nm);
   MDLM_CHECK_ARG(B >= 0 && L > 0 && V > 0 && ld >= V && (int64_t)B * L < (1ll << 31), "%s: bad shape B=%d L=%d V=%d ld=%lld", nm, B, L, V, (long long)ld);
   MDLM_CHECK_ARG(mask_index >= 0 && mask_index < V, "%s: mask_index out of range", nm);
@@ -739,13 +794,13 @@ static int launch_update(const void* src, int64_t ld, int dtype, float* lse,
   const unsigned rows = (unsigned)((int64_t)B * L);
   const float dtf = (float)dt;  // python float -> fp32 scalar, as torch does
 #define MDLM_UPD(T, FAST, PH) \
-  ddpm_update_kernel<T, SRC, FAST, PH><<<rows, NT, 0, s>>>((const T*)src, ld, lse, fresh, x, t, dtf, u, seed, offset, x_next, changed, L, V, mask_index)
+  ddpm_update_kernel<T, SRC, FAST, PH><<<rows, NT, 0, s>>>((const T*)src, ld, lse, fresh, x, t, dtf, q_scale, q_mask, u, seed, offset, x_next, changed, L, V, mask_index)
   const bool ph = (u == nullptr), fast = fast_math != 0;
   if (ph && fast) {
     if (dtype == MDLM_F32)
-      ddpm_update_fast_kernel<float, SRC><<<rows, NT, 0, s>>>((const float*)src, ld, lse, fresh, x, t, dtf, seed, offset, x_next, changed, L, V, mask_index);
+      ddpm_update_fast_kernel<float, SRC><<<rows, NT, 0, s>>>((const float*)src, ld, lse, fresh, x, t, dtf, q_scale, q_mask, seed, offset, x_next, changed, L, V, mask_index);
     else
-      ddpm_update_fast_kernel<bf16_t, SRC><<<rows, NT, 0, s>>>((const bf16_t*)src, ld, lse, fresh, x, t, dtf, seed, offset, x_next, changed, L, V, mask_index);
+      ddpm_update_fast_kernel<bf16_t, SRC><<<rows, NT, 0, s>>>((const bf16_t*)src, ld, lse, fresh, x, t, dtf, q_scale, q_mask, seed, offset, x_next, changed, L, V, mask_index);
   } else if (dtype == MDLM_F32) {
     if (ph) { if (fast) MDLM_UPD(float, true, true); else MDLM_UPD(float, false, true); }
     else    { if (fast) MDLM_UPD(float, true, false); else MDLM_UPD(float, false, false); }
@@ -764,7 +819,7 @@ extern "C" int mdlm_ddpm_cache_update(const void* p_x0, int64_t ld, int dtype,
                                       int64_t* x_next, int32_t* changed, int B,
                                       int L, int V, int mask_index, int fast_math,
                                       void* stream) {
-  return launch_update<0>(p_x0, ld, dtype, nullptr, nullptr, x, t, dt, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
+  return launch_update<0>(p_x0, ld, dtype, nullptr, nullptr, x, t, dt, nullptr, nullptr, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
 }
 
 extern "C" int mdlm_subs_ddpm_update(const void* logits, int64_t ld, int dtype,
@@ -775,7 +830,19 @@ extern "C" int mdlm_subs_ddpm_update(const void* logits, int64_t ld, int dtype,
                                      int64_t* x_next, int32_t* changed, int B,
                                      int L, int V, int mask_index, int fast_math,
                                      void* stream) {
-  return launch_update<1>(logits, ld, dtype, lse, fresh, x, t, dt, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
+  return launch_update<1>(logits, ld, dtype, lse, fresh, x, t, dt, nullptr, nullptr, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
+}
+
+extern "C" int mdlm_subs_race_update(const void* logits, int64_t ld, int dtype,
+                                     float* lse, const int32_t* fresh,
+                                     const int64_t* x, const float* q_scale,
+                                     const float* q_mask, const float* u,
+                                     uint64_t seed, uint64_t offset,
+                                     int64_t* x_next, int32_t* changed, int B,
+                                     int L, int V, int mask_index, int fast_math,
+                                     void* stream) {
+  MDLM_CHECK_ARG(q_scale && q_mask, "subs_race_update: q_scale / q_mask are required");
+  return launch_update<1>(logits, ld, dtype, lse, fresh, x, nullptr, 0.0, q_scale, q_mask, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
 }
 
 extern "C" int mdlm_philox_uniform(float* out, int64_t rows, int V, uint64_t seed,
@@ -843,6 +910,19 @@ extern "C" int mdlm_masked_row_map(const int64_t* x, const int32_t* active,
   MDLM_CHECK_ARG(x && active && n_active && gather && scatter && n_out, "masked_row_map: null pointer");
   MDLM_CHECK_ARG(L > 0 && pad > 0, "masked_row_map: bad shape");
   masked_row_map_kernel<<<1, 1024, 0, ST(stream)>>>(x, active, n_active, L, mask_index, pad, gather, scatter, n_out);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_d3pm_loss(const float* neg_logp_x0, const int64_t* xt,
+                              const float* t, int T, const float* attn_mask,
+                              float* out, int B, int L, int mask_index,
+                              void* stream) {
+  MDLM_CHECK_ARG(neg_logp_x0 && xt && t && out, "d3pm_loss: null pointer");
+  MDLM_CHECK_ARG(B >= 0 && L > 0 && T > 0, "d3pm_loss: bad shape / T");
+  const int64_t n = (int64_t)B * L;
+  if (n == 0) return 0;
+  d3pm_loss_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ST(stream)>>>(neg_logp_x0, xt, t, T, attn_mask, out, n, L, mask_index);
   MDLM_LAUNCH_CHECK();
   return 0;
 }

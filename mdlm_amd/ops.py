@@ -153,6 +153,45 @@ def subs_ddpm_update(logits, lse, x, t, dt, mask_index, u=None, seed=0,
   return x_next
 
 
+def subs_race_update(logits, lse, x, q_scale, q_mask, mask_index, u=None,
+                     seed=0, offset=0, changed=None, fast_math=False,
+                     x_next=None, fresh=None):
+  """Generic masked-row race (samplers 'ddpm' / 'analytic' / denoiser)."""
+  lg, rows, V, ld = _rows2d(logits, 'logits')
+  x = _dev(x, 'x', torch.int64).contiguous()
+  B, L = x.shape
+  assert rows == B * L
+  lse = _dev(lse, 'lse', torch.float32).contiguous()
+  assert lse.numel() == rows
+  qs = _dev(q_scale, 'q_scale').to(torch.float32).reshape(-1).contiguous()
+  qm = _dev(q_mask, 'q_mask').to(torch.float32).reshape(-1).contiguous()
+  assert qs.numel() == B and qm.numel() == B
+  if u is not None:
+    u = _dev(u, 'u', torch.float32).contiguous()
+    assert u.numel() == rows * V
+  if x_next is None:
+    x_next = torch.empty_like(x)
+  call('mdlm_subs_race_update', lg.data_ptr(), ld, _DT[lg.dtype],
+       lse.data_ptr(), _p(fresh), x.data_ptr(), qs.data_ptr(), qm.data_ptr(),
+       _p(u), int(seed), int(offset), x_next.data_ptr(), _p(changed), B, L, V,
+       int(mask_index), int(bool(fast_math)), _stream())
+  return x_next
+
+
+def d3pm_loss(neg_logp_x0, xt, t, T, mask_index, attn_mask=None):
+  nl = _dev(neg_logp_x0, 'neg_logp_x0', torch.float32).contiguous()
+  xt = _dev(xt, 'xt', torch.int64).contiguous()
+  B, L = xt.shape
+  tt = _dev(t, 't').to(torch.float32).reshape(-1).contiguous()
+  assert tt.numel() == B and nl.shape == xt.shape
+  if attn_mask is not None:
+    attn_mask = _dev(attn_mask, 'attn_mask').to(torch.float32).contiguous()
+  out = torch.empty(B, L, dtype=torch.float32, device=xt.device)
+  call('mdlm_d3pm_loss', nl.data_ptr(), xt.data_ptr(), tt.data_ptr(), int(T),
+       _p(attn_mask), out.data_ptr(), B, L, int(mask_index), _stream())
+  return out
+
+
 def philox_uniform(rows, V, seed, offset=0, device='cuda'):
   out = torch.empty(rows, V, dtype=torch.float32, device=device)
   call('mdlm_philox_uniform', out.data_ptr(), rows, V, int(seed), int(offset),

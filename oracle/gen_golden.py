@@ -147,7 +147,10 @@ def make_self(diffusion, noise_schedule, backbone, mask_index, vocab_size,
   D = diffusion.Diffusion
   for name in ('_process_sigma', '_subs_parameterization', 'forward', 'q_xt',
                '_sample_prior', '_ddpm_caching_update', '_sample_t',
-               '_maybe_sub_sample', '_forward_pass_diffusion', '_loss'):
+               '_maybe_sub_sample', '_forward_pass_diffusion', '_loss',
+               '_ddpm_update', 'get_score', '_staggered_score',
+               '_transp_transition', '_analytic_update', '_denoiser_update',
+               '_d3pm_loss'):
     setattr(ns, name, types.MethodType(getattr(D, name), ns))
   return ns
 
@@ -393,6 +396,46 @@ def main():
   np.savez(os.path.join(OUT, 'g8_semi_ar.npz'), seed=np.int64(81),
            sampling_steps=np.int64(steps), tokens=toks,
            seq_lens=np.asarray(seqlens), eos=np.int64(V - 2))
+  # ---------------- G9: 'ddpm' and 'analytic' samplers (tiny model) -------
+  g9 = {}
+  Bq, Lq = 2, tc.length
+  for tc_flag in (False, True):
+    tag0 = 'tc' if tc_flag else 'notc'
+    ns = make_self(diffusion, noise_schedule, ref, mask, V, Lq, Bq,
+                   time_conditioning=tc_flag)
+    torch.manual_seed(90)
+    x = torch.randint(0, V - 1, (Bq, Lq))
+    x[torch.rand(Bq, Lq) < 0.7] = mask
+    t = torch.tensor([[0.6], [0.25]])
+    dt = (1 - 1e-5) / 16
+    g9[f'{tag0}_x'] = x.numpy(); g9[f'{tag0}_t'] = t.numpy()
+    g9[f'{tag0}_dt'] = np.float64(dt)
+    for name, fn in (('ddpm', lambda: D._ddpm_update(ns, x, t, dt)),
+                     ('analytic', lambda: D._analytic_update(ns, x, t, dt)),
+                     ('denoiser', lambda: D._denoiser_update(ns, x, t))):
+      st = torch.get_rng_state(); u = torch.rand(Bq, Lq, V); torch.set_rng_state(st)
+      g9[f'{tag0}_{name}_u'] = u.numpy()
+      g9[f'{tag0}_{name}_out'] = fn().numpy()
+    for sampler, seed in (('ddpm', 91), ('analytic', 92)):
+      ns.sampler = sampler
+      torch.manual_seed(seed)
+      g9[f'{tag0}_{sampler}_sample_seed'] = np.int64(seed)
+      g9[f'{tag0}_{sampler}_sample'] = D._sample(ns, num_steps=16).numpy()
+  np.savez(os.path.join(OUT, 'g9_other_samplers.npz'), **g9)
+
+  # ---------------- G10: discrete-time (T > 0) SUBS loss ------------------
+  ns = make_self(diffusion, noise_schedule, ref, mask, V, tc.length, 2)
+  ns.T = 8
+  torch.manual_seed(101)
+  x0 = torch.randint(0, V - 1, (8, tc.length))
+  attn = torch.ones(8, tc.length)
+  st = torch.get_rng_state()
+  u_t = torch.rand(8); u_xt = torch.rand(8, tc.length)
+  torch.set_rng_state(st)
+  loss = D._loss(ns, x0, attn)
+  np.savez(os.path.join(OUT, 'g10_d3pm_loss.npz'), x0=x0.numpy(), attn=attn.numpy(),
+           u_t=u_t.numpy(), u_xt=u_xt.numpy(), T=np.int64(8),
+           nlls=loss.nlls.numpy(), token_nll=loss.loss.numpy())
   tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
   print('golden written to', OUT, 'bytes', tot)
 

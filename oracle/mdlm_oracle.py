@@ -112,6 +112,104 @@ def ddpm_caching_update(forward_fn, x, t, dt, u, mask_index, p_x0=None):
   return p_x0, copy_flag * x + (1 - copy_flag) * _x
 
 
+def ddpm_update(forward_fn, x, t, dt, u, mask_index):
+  """diffusion.py:612-637 (sampler == 'ddpm': no cache, sigma-conditioned)."""
+  sigma_t = loglinear_total_noise(t)
+  sigma_s = loglinear_total_noise(t - dt)
+  if sigma_t.ndim > 1:
+    sigma_t = sigma_t.squeeze(-1)
+  if sigma_s.ndim > 1:
+    sigma_s = sigma_s.squeeze(-1)
+  move_chance_t = (1 - torch.exp(-sigma_t))[:, None, None]
+  move_chance_s = (1 - torch.exp(-sigma_s))[:, None, None]
+  q_xs = forward_fn(x, sigma_t).exp() * (move_chance_t - move_chance_s)
+  q_xs[:, :, mask_index] = move_chance_s[:, :, 0]
+  _x = sample_categorical(q_xs, u)
+  copy_flag = (x != mask_index).to(x.dtype)
+  return copy_flag * x + (1 - copy_flag) * _x
+
+
+def get_score(forward_fn, x, sigma, mask_index, neg_infinity=NEG_INFINITY):
+  """diffusion.py:721-764 (subs branch): ratio p_t(y)/p_t(x) for every y."""
+  model_output = forward_fn(x, sigma)
+  log_k = -torch.log(torch.expm1(sigma)).squeeze(-1)
+  assert log_k.ndim == 1
+  masked_score = model_output + log_k[:, None, None]
+  masked_score[:, :, mask_index] = 0
+  unmasked_score = neg_infinity * torch.ones_like(model_output)
+  unmasked_score = torch.scatter(unmasked_score, -1, x[..., None],
+                                 torch.zeros_like(unmasked_score[..., :1]))
+  unmasked_score[:, :, mask_index] = -(log_k[:, None] * torch.ones_like(x))
+  masked = (x == mask_index).to(model_output.dtype)[:, :, None]
+  return (masked_score * masked + unmasked_score * (1 - masked)).exp()
+
+
+def staggered_score(score, dsigma, mask_index):
+  """diffusion.py:766-771."""
+  score = score.clone()
+  extra_const = (1 - dsigma.exp()) * score.sum(dim=-1)
+  score *= dsigma.exp()[:, None]
+  score[..., mask_index] += extra_const
+  return score
+
+
+def transp_transition(i, sigma, mask_index, vocab_size):
+  """diffusion.py:791-798 (sigma broadcast against i[..., None], utils 18-21)."""
+  sigma = sigma.view(*sigma.shape, *((1,) * (i[..., None].dim() - sigma.dim())))
+  edge = torch.exp(-sigma) * F.one_hot(i, num_classes=vocab_size)
+  edge += torch.where(i == mask_index, 1 - torch.exp(-sigma).squeeze(-1),
+                      0)[..., None]
+  return edge
+
+
+def analytic_update(forward_fn, x, t, step_size, u, mask_index, vocab_size):
+  """diffusion.py:773-780 (sampler == 'analytic')."""
+  curr_sigma = loglinear_total_noise(t)
+  next_sigma = loglinear_total_noise(t - step_size)
+  dsigma = curr_sigma - next_sigma
+  score = get_score(forward_fn, x, curr_sigma, mask_index)
+  stag_score = staggered_score(score, dsigma, mask_index)
+  probs = stag_score * transp_transition(x, dsigma, mask_index, vocab_size)
+  return sample_categorical(probs, u)
+
+
+def denoiser_update(forward_fn, x, t, u, mask_index, vocab_size):
+  """diffusion.py:782-789 (noise removal of the analytic sampler)."""
+  sigma = loglinear_total_noise(t)
+  score = get_score(forward_fn, x, sigma, mask_index)
+  stag_score = staggered_score(score, sigma, mask_index)
+  probs = stag_score * transp_transition(x, sigma, mask_index, vocab_size)
+  probs[..., mask_index] = 0
+  return sample_categorical(probs, u)
+
+
+def d3pm_loss(model_output, xt, x0, t, T, mask_index):
+  """diffusion.py:329-358 (discrete-time NELBO term, T > 0)."""
+  dt = 1 / T
+  t = t[:, None].clamp(0., 1. - 1e-4)
+  alpha_t = 1 - t + torch.zeros_like(xt)
+  alpha_s = 1 - (t - dt) + torch.zeros_like(xt)
+  log_x_theta_at_x0 = torch.gather(model_output, -1, x0[:, :, None]).squeeze(-1)
+  x_theta_at_m = model_output[:, :, mask_index].exp()
+  term_1_coef = dt / t
+  term_1_log_nr = torch.log(alpha_t * x_theta_at_m / t + 1)
+  term_1_log_dr = log_x_theta_at_x0
+  term_2_coef = 1 - dt / t
+  term_2_log_nr = term_1_log_nr
+  term_2_log_dr = torch.log(alpha_s * x_theta_at_m / (t - dt) + 1)
+  L_vb_masked = (term_1_coef * (term_1_log_nr - term_1_log_dr)
+                 + term_2_coef * (term_2_log_nr - term_2_log_dr))
+  return T * (L_vb_masked * (xt == mask_index))
+
+
+def discretize_t(t, T):
+  """diffusion.py:849-853: t -> {1/T, ..., 1} grid."""
+  t = (t * T).to(torch.int)
+  t = t / T
+  t += (1 / T)
+  return t
+
+
 # --------------------------------------------------------------------------
 # DiT backbone (models/dit.py), fp32, SDPA attention
 # --------------------------------------------------------------------------
@@ -253,7 +351,8 @@ class OracleDiffusion:
 
   def __init__(self, params, n_heads, n_blocks, vocab_size, mask_index,
                length, time_conditioning=False, sampling_eps=1e-3,
-               antithetic_sampling=True, rand_fn=None):
+               antithetic_sampling=True, rand_fn=None, sampler='ddpm_cache',
+               T=0):
     self.p = params
     self.n_heads, self.n_blocks = n_heads, n_blocks
     self.vocab_size, self.mask_index = vocab_size, mask_index
@@ -264,6 +363,8 @@ class OracleDiffusion:
     self.neg_infinity = NEG_INFINITY
     self.rand = rand_fn or (lambda *shape: torch.rand(*shape))
     self.nfe = 0
+    self.sampler = sampler
+    self.T = T
 
   def backbone(self, x, sigma):
     self.nfe += 1
@@ -292,23 +393,35 @@ class OracleDiffusion:
 
   def _sample(self, batch_size, num_steps, eps=1e-5, noise_removal=True,
               trace=None):
-    """diffusion.py:657-698 (sampler == 'ddpm_cache')."""
+    """diffusion.py:657-698 (samplers 'ddpm_cache', 'ddpm', 'analytic')."""
     x = self.mask_index * torch.ones(batch_size, self.length,
                                      dtype=torch.int64)
     timesteps = torch.linspace(1, eps, num_steps + 1)
     dt = (1 - eps) / num_steps
     p_x0_cache = None
+    shape_v = (batch_size, self.length, self.vocab_size)
     for i in range(num_steps):
       t = timesteps[i] * torch.ones(x.shape[0], 1)
-      p_x0_cache, x_next = self._ddpm_caching_update(x, t, dt, p_x0=p_x0_cache)
-      if (not torch.allclose(x_next, x)) or self.time_conditioning:
-        p_x0_cache = None
-      x = x_next
+      if self.sampler == 'ddpm':
+        x = ddpm_update(self.forward, x, t, dt, self.rand(*shape_v),
+                        self.mask_index)
+      elif self.sampler == 'ddpm_cache':
+        p_x0_cache, x_next = self._ddpm_caching_update(x, t, dt, p_x0=p_x0_cache)
+        if (not torch.allclose(x_next, x)) or self.time_conditioning:
+          p_x0_cache = None
+        x = x_next
+      else:
+        x = analytic_update(self.forward, x, t, dt, self.rand(*shape_v),
+                            self.mask_index, self.vocab_size)
       if trace is not None:
         trace.append(x.clone())
     if noise_removal:
       t = timesteps[-1] * torch.ones(x.shape[0], 1)
-      x = self.forward(x, loglinear_total_noise(t)).argmax(dim=-1)
+      if self.sampler == 'analytic':
+        x = denoiser_update(self.forward, x, t, self.rand(*shape_v),
+                            self.mask_index, self.vocab_size)
+      else:
+        x = self.forward(x, loglinear_total_noise(t)).argmax(dim=-1)
     return x
 
   def sample_subs_guidance(self, n_samples, stride_length, num_strides,
@@ -340,16 +453,21 @@ class OracleDiffusion:
     return sampling_steps, torch.cat(intermediate_tokens, dim=1)
 
   def _forward_pass_diffusion(self, x0, t=None, u_xt=None):
-    """diffusion.py:847-894, subs / T=0 / no change_of_variables branch."""
+    """diffusion.py:847-894, subs / no change_of_variables; T = 0 (continuous
+    time) or T > 0 (d3pm-style discrete-time term, reconstruction loss 0)."""
     if t is None:
       t = sample_t(x0.shape[0], self.rand(x0.shape[0]), self.sampling_eps,
                    self.antithetic_sampling)
+    if self.T > 0:
+      t = discretize_t(t, self.T)
     sigma, dsigma = loglinear_noise(t)
     move_chance = 1 - torch.exp(-sigma[:, None])
     if u_xt is None:
       u_xt = self.rand(*x0.shape)
     xt = q_xt(x0, move_chance, u_xt, self.mask_index)
     model_output = self.forward(xt, sigma[:, None])
+    if self.T > 0:
+      return d3pm_loss(model_output, xt, x0, t, self.T, self.mask_index), xt
     log_p_theta = torch.gather(model_output, -1, x0[:, :, None]).squeeze(-1)
     return -log_p_theta * (dsigma / torch.expm1(sigma))[:, None], xt
 

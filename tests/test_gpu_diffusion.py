@@ -233,6 +233,86 @@ def test_loss_matches_oracle(ops):
   assert abs(res['val/ppl'] - math.exp(res['val/nll'])) < 1e-6 * res['val/ppl']
 
 
+@pytest.mark.parametrize('sampler', ['ddpm', 'analytic'])
+@pytest.mark.parametrize('tcond', [False, True])
+def test_other_samplers_match_oracle(ops, sampler, tcond):
+  """`sampling.predictor` in {ddpm, analytic} (diffusion.py:612-637, 721-798):
+  the generic race kernel == the oracle's literal restatement (score ->
+  staggered score -> transition -> _sample_categorical) on the GPU backbone's
+  logits and the same Philox uniforms, token for token."""
+  model, cfg, p = make_model([f'sampling.predictor={sampler}',
+                              f'time_conditioning={str(tcond).lower()}'])
+  B, L, T = 3, cfg.model.length, 12
+  model.seed_rng(77)
+  out = model._sample(num_steps=T).cpu()
+  assert int(model.last_nfe.item()) == B * (T + 1)
+  od = GpuBackedOracle(model, ops, p, cfg.model.n_heads, cfg.model.n_blocks, V, MASK, L,
+                       time_conditioning=tcond, sampler=sampler)
+  od.seed = 77
+  od.rand = lambda *shape: od.draw(*shape)
+  ref = od._sample(B, T)
+  assert torch.equal(out, ref)
+  assert (out != MASK).all()
+
+
+def test_other_sampler_updates_with_supplied_noise(ops):
+  """API-level `_ddpm_update` / `_analytic_update` / `_denoiser_update` with a
+  caller-supplied uniform tensor (exact kernel path, no Philox)."""
+  model, cfg, p = make_model(['time_conditioning=true'])
+  B, L = 2, cfg.model.length
+  od = GpuBackedOracle(model, ops, p, cfg.model.n_heads, cfg.model.n_blocks, V, MASK, L,
+                       time_conditioning=True)
+  torch.manual_seed(4)
+  x = torch.randint(0, V - 1, (B, L)); x[torch.rand(B, L) < 0.7] = MASK
+  t = torch.tensor([[0.7], [0.2]])
+  dt = 0.05
+  for name in ('ddpm', 'analytic', 'denoiser'):
+    u = torch.rand(B, L, V)
+    if name == 'ddpm':
+      got = model._ddpm_update(x.cuda(), t.cuda(), dt, u=u.cuda())
+      ref = orc.ddpm_update(od.forward, x, t, dt, u, MASK)
+    elif name == 'analytic':
+      got = model._analytic_update(x.cuda(), t.cuda(), dt, u=u.cuda())
+      ref = orc.analytic_update(od.forward, x, t, dt, u, MASK, V)
+    else:
+      got = model._denoiser_update(x.cuda(), t.cuda(), u=u.cuda())
+      ref = orc.denoiser_update(od.forward, x, t, u, MASK, V)
+      assert (got != MASK).all()
+    assert torch.equal(got.cpu(), ref), name
+    assert torch.equal(got.cpu()[x != MASK], x[x != MASK])
+
+
+def test_d3pm_loss_matches_oracle(ops):
+  """T > 0 (diffusion.py:329-358, 849-853): discrete-time SUBS loss, including
+  the NaN rows the reference produces at t == 1/T."""
+  Tn = 8
+  model, cfg, p = make_model([f'T={Tn}'])
+  B, L = 8, cfg.model.length
+  torch.manual_seed(6)
+  x0 = torch.randint(0, V - 1, (B, L))
+  attn = torch.ones(B, L); attn[2, -4:] = 0
+  t = orc.sample_t(B, torch.rand(B))
+  u = torch.rand(B, L)
+  loss = model._loss(x0.cuda(), attn.cuda(), t=t.cuda(), u=u.cuda())
+  od = orc.OracleDiffusion(p, cfg.model.n_heads, cfg.model.n_blocks, V, MASK, L, T=Tn)
+  tok_ref, nll_ref, _ = od._loss(x0, attn, t=t, u_xt=u)
+  got = loss.nlls.cpu()
+  assert torch.equal(got.isnan(), nll_ref.isnan())
+  assert nll_ref.isnan().any() and not nll_ref.isnan().all()   # both kinds of rows are covered
+  ok = ~nll_ref.isnan()
+  err = (got[ok] - nll_ref[ok]).abs() / nll_ref[ok].abs().clamp(min=1.0)
+  assert err.max().item() < 5e-2
+  assert math.isnan(loss.loss.item()) == math.isnan(tok_ref.item())
+  # the kernel alone, fp32 inputs from the oracle: tight tolerance
+  lp = torch.randn(B, L).abs()
+  xt = torch.where(torch.rand(B, L) < 0.5, torch.full((B, L), MASK), x0)
+  tt = orc.discretize_t(t, Tn)
+  mo = torch.full((B, L, V), -1e6); mo.scatter_(-1, x0[:, :, None], -lp[:, :, None])
+  ref = orc.d3pm_loss(mo, xt, x0, tt, Tn, MASK)
+  out = ops.d3pm_loss(lp.cuda(), xt.cuda(), tt.cuda(), Tn, MASK).cpu()
+  torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6, equal_nan=True)
+
+
 def test_out_of_scope_is_loud():
   from mdlm_amd.config import load_config
   from mdlm_amd.diffusion import Diffusion
@@ -241,7 +321,7 @@ def test_out_of_scope_is_loud():
   with pytest.raises(NotImplementedError):
     Diffusion(load_config(['model=tiny', 'parameterization=sedd']), tok)
   with pytest.raises(NotImplementedError):
-    Diffusion(load_config(['model=tiny', 'T=1000']), tok)
+    Diffusion(load_config(['model=tiny', 'training.importance_sampling=true']), tok)
   with pytest.raises(ValueError):
     Diffusion(load_config(['model=tiny', 'backbone=dimamba']), tok)
   model, cfg, _ = make_model()

@@ -178,3 +178,43 @@ def test_g8_semi_ar():
   steps, toks = od.sample_subs_guidance(2, 8, 2, dt=1 / 8)
   assert steps == int(g['sampling_steps'])
   assert torch.equal(toks, _t(g['tokens']))
+
+
+def test_g9_other_samplers():
+  """'ddpm' / 'analytic' samplers (diffusion.py:612-637, 721-798)."""
+  g = _g('g9_other_samplers.npz')
+  tc, p = _tiny()
+  V, mask = tc.vocab, tc.vocab - 1
+  for tag0, tcond in (('notc', False), ('tc', True)):
+    od = orc.OracleDiffusion(p, tc.n_heads, tc.n_blocks, V, mask, tc.length,
+                             time_conditioning=tcond)
+    x, t, dt = _t(g[f'{tag0}_x']), _t(g[f'{tag0}_t']), float(g[f'{tag0}_dt'])
+    out = orc.ddpm_update(od.forward, x, t, dt, _t(g[f'{tag0}_ddpm_u']), mask)
+    assert torch.equal(out, _t(g[f'{tag0}_ddpm_out'])), tag0
+    out = orc.analytic_update(od.forward, x, t, dt, _t(g[f'{tag0}_analytic_u']),
+                              mask, V)
+    assert torch.equal(out, _t(g[f'{tag0}_analytic_out'])), tag0
+    out = orc.denoiser_update(od.forward, x, t, _t(g[f'{tag0}_denoiser_u']),
+                              mask, V)
+    assert torch.equal(out, _t(g[f'{tag0}_denoiser_out'])), tag0
+    for sampler in ('ddpm', 'analytic'):
+      od = orc.OracleDiffusion(p, tc.n_heads, tc.n_blocks, V, mask, tc.length,
+                               time_conditioning=tcond, sampler=sampler)
+      torch.manual_seed(int(g[f'{tag0}_{sampler}_sample_seed']))
+      final = od._sample(2, 16)
+      assert torch.equal(final, _t(g[f'{tag0}_{sampler}_sample'])), (tag0, sampler)
+
+
+def test_g10_d3pm_loss():
+  """Discrete-time (T > 0) SUBS loss (diffusion.py:329-358, 849-853, 874-881)."""
+  g = _g('g10_d3pm_loss.npz')
+  tc, p = _tiny()
+  od = orc.OracleDiffusion(p, tc.n_heads, tc.n_blocks, tc.vocab, tc.vocab - 1,
+                           tc.length, T=int(g['T']))
+  t = orc.sample_t(8, _t(g['u_t']))
+  token_nll, nlls, _ = od._loss(_t(g['x0']), _t(g['attn']), t=t,
+                                u_xt=_t(g['u_xt']))
+  torch.testing.assert_close(nlls, _t(g['nlls']), rtol=1e-5, atol=1e-5,
+                             equal_nan=True)
+  torch.testing.assert_close(token_nll, _t(g['token_nll']), rtol=1e-5,
+                             atol=1e-6, equal_nan=True)
