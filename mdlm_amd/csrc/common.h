@@ -40,8 +40,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   __bf16 b = (__bf16)f;
   return *reinterpret_cast<bf16_t*>(&b);
 }
+// one v_cvt_pk_bf16_f32 for the pair (two scalar casts make hipcc pair values
+// of different words and re-shuffle them with and/shift/or)
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+  return *reinterpret_cast<const unsigned*>(&b);
 }
 
 template <typename T> struct elem;

@@ -63,7 +63,25 @@ __device__ __forceinline__ float gelu_tanh(float x) {
   return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(z2));
 }
 
+// the same on a pair: five packed fp32 ops + 2 x (v_exp_f32, v_rcp_f32)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
+  const f32x2 k1 = {-2.3022082f * 0.044715f, -2.3022082f * 0.044715f};
+  const f32x2 k0 = {-2.3022082f, -2.3022082f};
+  const f32x2 one = {1.f, 1.f};
+  const f32x2 w = x * __builtin_elementwise_fma(x * x, k1, k0);
+  const f32x2 e = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
+  const f32x2 d = e + one;
+  const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  return x * r;
+}
+
 __device__ __forceinline__ float bf16_round(float x) { return bf16_to_f32(f32_to_bf16(x)); }
+// round a pair to bf16 and back: one v_cvt_pk_bf16_f32 + shift + and
+__device__ __forceinline__ f32x2 bf16_round2(float a, float b) {
+  const unsigned u = pack_bf16x2(a, b);
+  return (f32x2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
 
 // 16-byte row store of the epilogue.  bf16 outputs (q/k, MLP hidden, logits)
 // are written once and read by a later kernel: non-temporal stores keep them
@@ -118,17 +136,26 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
     bf16_t* const base = reinterpret_cast<bf16_t*>(g.C) + (int64_t)three * g.M * g.n_heads * 64;
     if (three == 2) {
       // NATURAL accumulators here: acc(m, n)[j] = C[m*16 + fq*4 + j][n*16 + fr];
-      // v^T[b,h,d,l]: 4 consecutive l for one d -> 8-byte stores
-      bf16_t* const vb = base + ((b * g.n_heads + h) * 64) * L + pos0;
+      // v^T[b,h,d,l]: a lane holds 4 consecutive l of one d.  Transposed
+      // through the LDS tile [64 d][64 l] (16-B chunk swizzled by d & 7) so the
+      // global stores are whole 128-byte rows of v^T.
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           const int d = n * 16 + fr;
-          *reinterpret_cast<uint2*>(vb + (int64_t)d * L + m * 16 + fq * 4) =
+          const int c16 = m * 2 + (fq >> 1);
+          *reinterpret_cast<uint2*>(ep + d * 128 + ((c16 ^ (d & 7)) * 16) + (fq & 1) * 8) =
             make_uint2(pack_bf16x2(acc(m, n)[0], acc(m, n)[1]),
                        pack_bf16x2(acc(m, n)[2], acc(m, n)[3]));
         }
+      bf16_t* const vb = base + ((b * g.n_heads + h) * 64) * L + pos0;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int d = it * 8 + (lane >> 3), ch = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(ep + d * 128 + ((ch ^ (d & 7)) * 16));
+        store16<true>(vb + (int64_t)d * L + ch * 8, v, g.dbg);
+      }
       return;
     }
     // q / k: rotary in registers.  d = n*16 + fq*4 + j pairs with d + 32
@@ -149,15 +176,19 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
       const int row = m * 16 + fr;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        const float4 c4 = cs[m][n], s4 = sn[m][n];
-        const float a0 = bf16_round(acc(m, n)[0]), a1 = bf16_round(acc(m, n)[1]);
-        const float a2 = bf16_round(acc(m, n)[2]), a3 = bf16_round(acc(m, n)[3]);
-        const float b0 = bf16_round(acc(m, n + 2)[0]), b1 = bf16_round(acc(m, n + 2)[1]);
-        const float b2 = bf16_round(acc(m, n + 2)[2]), b3 = bf16_round(acc(m, n + 2)[3]);
-        const uint2 lo = make_uint2(pack_bf16x2(a0 * c4.x - b0 * s4.x, a1 * c4.y - b1 * s4.y),
-                                    pack_bf16x2(a2 * c4.z - b2 * s4.z, a3 * c4.w - b3 * s4.w));
-        const uint2 hi = make_uint2(pack_bf16x2(a0 * s4.x + b0 * c4.x, a1 * s4.y + b1 * c4.y),
-                                    pack_bf16x2(a2 * s4.z + b2 * c4.z, a3 * s4.w + b3 * c4.w));
+        // packed fp32 math on column pairs (0,1) and (2,3)
+        const f32x2 c01 = {cs[m][n].x, cs[m][n].y}, c23 = {cs[m][n].z, cs[m][n].w};
+        const f32x2 s01 = {sn[m][n].x, sn[m][n].y}, s23 = {sn[m][n].z, sn[m][n].w};
+        const f32x2 a01 = bf16_round2(acc(m, n)[0], acc(m, n)[1]);
+        const f32x2 a23 = bf16_round2(acc(m, n)[2], acc(m, n)[3]);
+        const f32x2 b01 = bf16_round2(acc(m, n + 2)[0], acc(m, n + 2)[1]);
+        const f32x2 b23 = bf16_round2(acc(m, n + 2)[2], acc(m, n + 2)[3]);
+        const f32x2 l01 = __builtin_elementwise_fma(a01, c01, -(b01 * s01));
+        const f32x2 l23 = __builtin_elementwise_fma(a23, c23, -(b23 * s23));
+        const f32x2 h01 = __builtin_elementwise_fma(a01, s01, b01 * c01);
+        const f32x2 h23 = __builtin_elementwise_fma(a23, s23, b23 * c23);
+        const uint2 lo = make_uint2(pack_bf16x2(l01.x, l01.y), pack_bf16x2(l23.x, l23.y));
+        const uint2 hi = make_uint2(pack_bf16x2(h01.x, h01.y), pack_bf16x2(h23.x, h23.y));
         // bf16 tile [64][64], 16-B chunk index swizzled by (row & 7)
         const int c_lo = n * 2 + (fq >> 1), c_hi = c_lo + 4;
         *reinterpret_cast<uint2*>(ep + row * 128 + ((c_lo ^ (row & 7)) * 16) + (fq & 1) * 8) = lo;
@@ -203,14 +234,12 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
           const int row = m * 16 + fr;
 #pragma unroll
           for (int n = 0; n < 4; ++n) {
-            float v0 = acc(m, n)[0] + ec.bias4[n].x, v1 = acc(m, n)[1] + ec.bias4[n].y;
-            float v2 = acc(m, n)[2] + ec.bias4[n].z, v3 = acc(m, n)[3] + ec.bias4[n].w;
-            if constexpr (EPI == MDLM_EPI_BIAS_GELU) {
-              v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
-            }
+            f32x2 lo = {acc(m, n)[0] + ec.bias4[n].x, acc(m, n)[1] + ec.bias4[n].y};
+            f32x2 hi = {acc(m, n)[2] + ec.bias4[n].z, acc(m, n)[3] + ec.bias4[n].w};
+            if constexpr (EPI == MDLM_EPI_BIAS_GELU) { lo = gelu_tanh2(lo); hi = gelu_tanh2(hi); }
             const int c16 = n * 2 + (fq >> 1);
             *reinterpret_cast<uint2*>(ep + row * 128 + ((c16 ^ (row & 7)) * 16) + (fq & 1) * 8) =
-              make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+              make_uint2(pack_bf16x2(lo.x, lo.y), pack_bf16x2(hi.x, hi.y));
           }
         }
 #pragma unroll
