@@ -222,9 +222,12 @@ int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
                    const int32_t* m_rows_dev, const int32_t* out_sample_map,
                    const int32_t* out_row_map, void* stream);
 
-/* Test hook, no reference counterpart: force_small != 0 makes mdlm_gemm_bf16
- * always use its 128x128 tile (default: 256x256 when M % 256 == 0 and
- * N >= 256) so that both configurations can be parity-tested on any shape. */
+/* Test hook, no reference counterpart: bit 0 of force_small makes
+ * mdlm_gemm_bf16 always use its 128x128 tile (default: 256x256 when
+ * M % 256 == 0 and N >= 256) so that both configurations can be parity-tested
+ * on any shape.  Bits 1 and 2 are timing ablations used by scratch/bench_gemm.py
+ * only (2: skip the epilogue, 4: run the epilogue but drop its global stores);
+ * outputs are then undefined. */
 int mdlm_gemm_set_tile(int force_small);
 
 /* Bidirectional attention, dit.py:265-275 (flash_attn_varlen_qkvpacked_func,

@@ -61,7 +61,9 @@ def check(M=4096):
     outs[mode] = (qkv, x, m1, lg)
   a, b = outs[modes[0]], outs[modes[-1]]
   print('check maxdiff:', [float((p.float() - q.float()).abs().max()) for p, q in zip(a, b)])
+import os
+Ms = [int(m) for m in os.environ.get('MS', '65536').split(',')]
 check()
-for M in (65536,):
+for M in Ms:
   for mode in modes:
     run(M, mode)

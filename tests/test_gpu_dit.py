@@ -174,19 +174,31 @@ def _qkv_ref(h, Wqkv, B, L, H):
   return _bf(rot).float()
 
 
-def test_gemm_qkv_rotary_layout(ops):
+@pytest.mark.parametrize('H', [1, 2, 3, 12])
+def test_gemm_qkv_rotary_layout(ops, H):
+  """q/k rotary + v^T layout; N = 3*H*64 is not a multiple of the 256-wide
+  tile for H in {1, 2, 3}: wave tiles past the N edge must write nothing
+  (guard bands on both sides of the output stay intact) and the result must
+  not depend on the run."""
   from mdlm_amd._lib import EPI_QKV_ROTARY
   torch.manual_seed(5)
-  B, L, H = 2, 256, 2
+  B, L = 2, 256
   D = H * 64
   M = B * L
   h = torch.randn(M, D); Wqkv = torch.randn(3 * D, D) * 0.1
   ref = _qkv_ref(h, Wqkv, B, L, H)            # (B, L, 3, H, 64)
   cos, sin = orc.rotary_cos_sin(L, 64)
-  out = torch.zeros(3 * M * D, dtype=torch.bfloat16, device='cuda')
-  ops.gemm_bf16(_bf(h).cuda(), _bf(Wqkv).cuda(), out, EPI_QKV_ROTARY, rows_per_mod=L,
-                rot_cos=_bf(cos).float().cuda(), rot_sin=_bf(sin).float().cuda(),
-                n_heads=H, ldc=0)
+  G = 4096
+  buf = torch.full((G + 3 * M * D + G,), 7.0, dtype=torch.bfloat16, device='cuda')
+  out = buf[G:G + 3 * M * D]
+  args = dict(rows_per_mod=L, rot_cos=_bf(cos).float().cuda(),
+              rot_sin=_bf(sin).float().cuda(), n_heads=H, ldc=0)
+  ops.gemm_bf16(_bf(h).cuda(), _bf(Wqkv).cuda(), out, EPI_QKV_ROTARY, **args)
+  first = out.clone()
+  assert (buf[:G] == 7.0).all() and (buf[G + 3 * M * D:] == 7.0).all()
+  for _ in range(3):
+    ops.gemm_bf16(_bf(h).cuda(), _bf(Wqkv).cuda(), out, EPI_QKV_ROTARY, **args)
+    assert torch.equal(out, first)
   o = out.float().cpu()
   q = o[:M * D].view(B, H, L, 64)
   k = o[M * D:2 * M * D].view(B, H, L, 64)
