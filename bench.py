@@ -247,7 +247,7 @@ def main():
   if not args.no_eval:
     # second half of the metric: NELBO eval tokens/s (q_xt + backbone + fused
     # SUBS-NLL + fp64 sums; sequences sharded by rank, one all-reduce at the end)
-    eb = 32
+    eb = 64
     g = torch.Generator(device='cuda').manual_seed(1 + rank)
     ids = torch.randint(0, V - 1, (eb, L), generator=g, device='cuda')
     ids[:, 0] = 50256; ids[:, -1] = 50256

@@ -124,6 +124,7 @@ class Diffusion(_Base):
     self._rng_seed = mdist.rank_seed(self.config.seed, mdist.env_rank()[0])
     self._rng_offset = 0
     self._state = None
+    self._eval_state = None
     self.last_nfe = None
 
   # ---------------------------------------------------------------- helpers
@@ -185,12 +186,33 @@ class Diffusion(_Base):
     assert sigma.ndim == 1, sigma.shape
     return sigma
 
-  def _backbone_logits(self, x, sigma):
+  def _backbone_logits(self, x, sigma, masked_rows_only=False):
+    """Backbone logits (B, L, V) bf16.  masked_rows_only: the caller reads
+    logits of masked positions only (NELBO: unmasked rows contribute exactly 0,
+    diffusion.py:270-277), so the final LayerNorm + vocabulary projection run
+    on those rows alone; the other rows of the result are uninitialised."""
     sigma = self._process_sigma(sigma)
-    out = ops.alloc_logits(x.shape[0], x.shape[1], self.vocab_size,
-                           torch.bfloat16, x.device)
-    return self.backbone.run(x.contiguous(), sigma, out,
-                             sigma_is_zero=not self.time_conditioning)
+    B, Lq = x.shape
+    x = x.contiguous()
+    out = ops.alloc_logits(B, Lq, self.vocab_size, torch.bfloat16, x.device)
+    row_map = None
+    if (masked_rows_only and not self.time_conditioning and (B * Lq) % 256 == 0
+        and self.config.sampling.get('masked_rows_only', True)):
+      es = self._eval_state
+      if es is None or es['B'] != B or es['L'] != Lq or es['dev'] != x.device:
+        i32 = dict(dtype=torch.int32, device=x.device)
+        es = dict(B=B, L=Lq, dev=x.device, ident=torch.arange(B, **i32),
+                  n=torch.full((1,), B, **i32),
+                  gather=torch.zeros(B * Lq + 256, **i32),
+                  scatter=torch.zeros(B * Lq + 256, **i32),
+                  n_mrows=torch.zeros(1, **i32))
+        self._eval_state = es
+      ops.masked_row_map(x, es['ident'], es['n'], Lq, self.mask_index,
+                         es['gather'], es['scatter'], es['n_mrows'])
+      row_map = (es['gather'], es['scatter'], es['n_mrows'])
+    return self.backbone.run(x, sigma, out,
+                             sigma_is_zero=not self.time_conditioning,
+                             row_map=row_map)
 
   def forward(self, x, sigma):
     """Returns log score (diffusion.py:312-327): SUBS log-probs (B, L, V)."""
@@ -533,7 +555,7 @@ class Diffusion(_Base):
     sigma, dsigma = self.noise(t)
     move_chance = 1 - torch.exp(-sigma[:, None])
     xt = self.q_xt(x0, move_chance, u=u)
-    logits = self._backbone_logits(xt, sigma[:, None])
+    logits = self._backbone_logits(xt, sigma[:, None], masked_rows_only=True)
     if self.T > 0:
       neg_logp = ops.subs_nll(logits, xt, x0, torch.ones_like(sigma),
                               self.mask_index)
