@@ -468,24 +468,37 @@ void gemm_bf16_kernel(GemmArgs g) {
         }
         const char* At = smem + buf * STAGE + a_base;
         const char* Bt = smem + buf * STAGE + b_base;
+        bf16x8 af[2][MT], bfr[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 af[MT], bfr[4];
 #pragma unroll
           for (int n = 0; n < 4; ++n)
-            bfr[n] = *reinterpret_cast<const bf16x8*>(Bt + n * 2048 + foff[ks]);
+            bfr[ks][n] = *reinterpret_cast<const bf16x8*>(Bt + n * 2048 + foff[ks]);
 #pragma unroll
           for (int m = 0; m < MT; ++m)
-            af[m] = *reinterpret_cast<const bf16x8*>(At + m * 2048 + foff[ks]);
+            af[ks][m] = *reinterpret_cast<const bf16x8*>(At + m * 2048 + foff[ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
               if constexpr (NAT)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][m], bfr[ks][n], acc[m][n], 0, 0, 0);
               else
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[n], af[m], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][n], af[ks][m], acc[m][n], 0, 0, 0);
             }
+        // fragment reads run ahead of the MFMA groups that consume them:
+        // 12 reads up front, then one read behind every group of 4 MFMAs
+        if constexpr (MT == 8) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+          for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         }
         __syncthreads();
         buf ^= 1;
@@ -500,17 +513,22 @@ void gemm_bf16_kernel(GemmArgs g) {
     // ---- epilogue through this wave's 8 KiB of the stage read last ----------
     // (dbg bit 2, timing experiments only: skip it)
     if (!(g.dbg & 2)) {
+      // launder the lane id: the epilogue's per-lane addresses are then
+      // recomputed per tile instead of being hoisted out of the tile loop and
+      // spilled (their reloads would sit between the stores)
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
       char* ep = smem + (buf ^ 1) * STAGE + wid * 8192;
       const int64_t growW = m0 + wr * (MT * 16);
       if constexpr (BF16_OUT) {
-        epilogue_sub<EPI, TC, MT, 0, 4>(acc, ep, growW, gcol0, ec, g, lane);
-        if constexpr (MT == 8) epilogue_sub<EPI, TC, MT, 4, 4>(acc, ep, growW + 64, gcol0, ec, g, lane);
+        epilogue_sub<EPI, TC, MT, 0, 4>(acc, ep, growW, gcol0, ec, g, lane_e);
+        if constexpr (MT == 8) epilogue_sub<EPI, TC, MT, 4, 4>(acc, ep, growW + 64, gcol0, ec, g, lane_e);
       } else {
-        epilogue_sub<EPI, TC, MT, 0, 2>(acc, ep, growW, gcol0, ec, g, lane);
-        epilogue_sub<EPI, TC, MT, 2, 2>(acc, ep, growW + 32, gcol0, ec, g, lane);
+        epilogue_sub<EPI, TC, MT, 0, 2>(acc, ep, growW, gcol0, ec, g, lane_e);
+        epilogue_sub<EPI, TC, MT, 2, 2>(acc, ep, growW + 32, gcol0, ec, g, lane_e);
         if constexpr (MT == 8) {
-          epilogue_sub<EPI, TC, MT, 4, 2>(acc, ep, growW + 64, gcol0, ec, g, lane);
-          epilogue_sub<EPI, TC, MT, 6, 2>(acc, ep, growW + 96, gcol0, ec, g, lane);
+          epilogue_sub<EPI, TC, MT, 4, 2>(acc, ep, growW + 64, gcol0, ec, g, lane_e);
+          epilogue_sub<EPI, TC, MT, 6, 2>(acc, ep, growW + 96, gcol0, ec, g, lane_e);
         }
       }
     } else if (acc[0][0][0] == 123.456f) {
