@@ -279,6 +279,22 @@ def main():
       'nfe_per_sample': round(int(model.last_nfe.item()) / B, 1)}
     cfg.sampling.cache_policy = args.cache_policy
 
+  if rank == 0 and world == 1 and not args.no_policy_compare and args.cache_policy == 'sample':
+    # opt-in two-stage step: same distribution as the reference step, not
+    # bit-identical to it on a shared uniform tensor -> never the headline value
+    cfg.sampling.lazy_unmask = True
+    model.restore_model_and_sample(num_steps=args.T)   # warm-up (state rebuild)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    model.restore_model_and_sample(num_steps=args.T)
+    torch.cuda.synchronize(); tb = time.perf_counter() - t1
+    out['lazy_unmask_mode'] = {
+      'note': ('sampling.lazy_unmask=true: Bernoulli unmask decision, then a categorical draw and the '
+               'vocabulary projection for the unmasking rows only; distribution-identical to '
+               'diffusion.py:592-610, NOT bit-identical to the reference race on a shared uniform tensor'),
+      'value': round(B / tb, 4), 'unit': 'samples/s',
+      'nfe_per_sample': round(int(model.last_nfe.item()) / B, 1)}
+    cfg.sampling.lazy_unmask = False
+
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     del model
     torch.cuda.empty_cache()

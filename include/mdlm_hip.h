@@ -130,6 +130,34 @@ int mdlm_d3pm_loss(const float* neg_logp_x0, const int64_t* xt, const float* t,
                    int T, const float* attn_mask, float* out, int B, int L,
                    int mask_index, void* stream);
 
+/* ---- opt-in two-stage ("lazy") ddpm_cache step; no reference counterpart ----
+ * The race of diffusion.py:592-610 leaves a masked position masked with
+ * probability (t - dt)/t and otherwise draws its token from p_x0.  Stage 1
+ * (mdlm_lazy_select) makes that Bernoulli decision with one Philox uniform per
+ * position: x_next = x, rows[0..n) = positions that unmask (padded with row 0
+ * up to a multiple of `pad`), n_rows[0] = padded count, n_rows[1] = n,
+ * changed[b] = 1 if sample b unmasks anything.  Stage 2 (mdlm_lazy_race) draws
+ * x_next[rows[i]] from softmax(logits row i) over v != mask; logits is the dense
+ * (max_rows, ld) output of the vocabulary projection of those rows only.
+ * Distribution-identical to the reference step, NOT bit-identical to it on a
+ * shared uniform tensor (a different map from random numbers to outcomes):
+ * `sampling.lazy_unmask=true` only. */
+int mdlm_lazy_select(const int64_t* x, const float* t, double dt, uint64_t seed,
+                     uint64_t offset, int B, int L, int mask_index, int pad,
+                     int64_t* x_next, int32_t* rows, int32_t* n_rows,
+                     int32_t* changed, void* stream);
+int mdlm_lazy_race(const void* logits, int64_t ld, int dtype, const int32_t* rows,
+                   const int32_t* n_rows, int max_rows, uint64_t seed,
+                   uint64_t offset, int64_t* x_next, int V, int mask_index,
+                   void* stream);
+/* dst[sample_map[r / L] * L + r % L] = src[r] for r < *n_rows_dev (fp32 rows of
+ * D elements): writes the residual stream of the compacted active samples back
+ * to a per-sample hidden-state cache (lazy sampler; SURVEY 8(f)-1 "cache the
+ * (B, L, 768) final hidden state instead of (B, L, V) p_x0"). */
+int mdlm_scatter_rows_f32(const float* src, float* dst, const int32_t* sample_map,
+                          int L, int D, int64_t n_rows, const int32_t* n_rows_dev,
+                          void* stream);
+
 /* The uniforms the in-kernel generator uses, materialised (rows, V) fp32, so
  * that tests can feed the oracle the same draw.  Test/diagnostic helper; no
  * reference counterpart (the reference calls torch.rand_like, diffusion.py:27). */

@@ -53,7 +53,7 @@ DEFAULTS = dict(
                 stride_length=1, num_strides=1,
                 # mdlm_amd extensions (result-identical knobs)
                 fused=True, cache_policy='sample', fast_math=True,
-                masked_rows_only=True,
+                masked_rows_only=True, lazy_unmask=False,
                 p_x0_dtype='bf16'),
   training=dict(ema=0.9999, antithetic_sampling=True,
                 importance_sampling=False, sampling_eps=1e-3,

@@ -24,6 +24,23 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(
   for (int i = lane; i < D / 4; i += 64) d[i] = s[i];
 }
 
+// dst[sample_map[r / L] * L + r % L] = src[r]: the residual stream of the
+// compacted active samples back to its per-sample home (hidden-state cache of
+// the opt-in lazy sampler).
+__global__ __launch_bounds__(256) void scatter_rows_kernel(
+    const float* __restrict__ src, float* __restrict__ dst,
+    const int32_t* __restrict__ sample_map, int L, int D, int64_t n_rows,
+    const int32_t* __restrict__ n_rows_dev) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t live = n_rows_dev ? (int64_t)*n_rows_dev : n_rows;
+  if (r >= n_rows || r >= live) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t d = sample_map ? (int64_t)sample_map[r / L] * L + (r % L) : r;
+  const float4* s = reinterpret_cast<const float4*>(src + r * D);
+  float4* o = reinterpret_cast<float4*>(dst + d * D);
+  for (int i = lane; i < D / 4; i += 64) o[i] = s[i];
+}
+
 __global__ void timestep_embedding_kernel(const float* __restrict__ t,
                                           float* __restrict__ out, int B, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,6 +184,18 @@ extern "C" int mdlm_ln_modulate(const float* x, const float* ln_w,
   MDLM_CHECK_ARG((((uintptr_t)x | (uintptr_t)ln_w | (uintptr_t)shift | (uintptr_t)scale | (uintptr_t)out_bf16) & 15) == 0, "ln_modulate: buffers must be 16-byte aligned");
   if (rows == 0) return 0;
   ln_modulate_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, ST(stream)>>>(x, ln_w, shift, scale, (bf16_t*)out_bf16, rows, D, rows_per_mod, n_mod, mod_ld, row_gather, n_rows_dev);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_scatter_rows_f32(const float* src, float* dst,
+                                     const int32_t* sample_map, int L, int D,
+                                     int64_t n_rows, const int32_t* n_rows_dev,
+                                     void* stream) {
+  MDLM_CHECK_ARG(src && dst && L > 0 && D > 0 && D % 4 == 0 && n_rows >= 0, "scatter_rows_f32: bad args");
+  MDLM_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "scatter_rows_f32: 16-byte alignment");
+  if (n_rows == 0) return 0;
+  scatter_rows_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, ST(stream)>>>(src, dst, sample_map, L, D, n_rows, n_rows_dev);
   MDLM_LAUNCH_CHECK();
   return 0;
 }

@@ -697,6 +697,107 @@ __global__ __launch_bounds__(1024) void masked_row_map_kernel(
   if (threadIdx.x == 0) *n_out = np;
 }
 
+// ---- opt-in two-stage ("lazy") ddpm_cache step --------------------------------
+// The reference race over {q_v = p_v (t - s)} U {q_mask = s} leaves a masked
+// position masked with probability s/t and otherwise draws its token from p_x0
+// (sum_v p_v = 1, the mask column of a SUBS output is 0).  Stage 1 makes that
+// Bernoulli decision with ONE uniform per masked position and lists the
+// positions that unmask; stage 2 (lazy_race_kernel) draws their tokens from
+// logits computed for those rows only.  Same distribution as
+// diffusion.py:592-610, different mapping from random numbers to outcomes, so
+// it is NOT bit-identical to the reference on a shared uniform tensor: opt-in.
+__global__ __launch_bounds__(1024) void lazy_select_kernel(
+    const int64_t* __restrict__ x, const float* __restrict__ t, float dt,
+    uint64_t seed, uint64_t offset, int n_rows, int L, int mask, int pad,
+    int64_t* __restrict__ x_next, int32_t* __restrict__ rows_out,
+    int32_t* __restrict__ n_out, int32_t* __restrict__ changed) {
+  constexpr int RPT = 8;
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < n_rows; r0 += 1024 * RPT) {
+    const int rbeg = r0 + threadIdx.x * RPT;   // RPT = 8 rows = two Philox groups
+    unsigned on = 0;
+    if (rbeg < n_rows) {
+      const uint4 ra = Philox::gen(seed, offset + (uint64_t)(rbeg >> 2));
+      const uint4 rb = Philox::gen(seed, offset + (uint64_t)(rbeg >> 2) + 1);
+      const unsigned rr[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+      for (int c = 0; c < RPT; ++c) {
+        const int r = rbeg + c;
+        if (r < n_rows) {
+          const int64_t tok = x[r];
+          x_next[r] = tok;
+          if (tok == mask) {
+            const float mt = t[r / L];
+            const float ms = mt - dt;                 // diffusion.py:599
+            // P(stay masked) = ms / mt  (diffusion.py:605-607)
+            if (!(Philox::u01(rr[c]) * mt < ms)) on |= 1u << c;
+          }
+        }
+      }
+    }
+    const int cnt = __popc(on);
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int off = base_s + incl - cnt;
+    for (int k = 0; k < w; ++k) off += wsum[k];
+#pragma unroll
+    for (int c = 0; c < RPT; ++c)
+      if (on & (1u << c)) {
+        rows_out[off++] = rbeg + c;
+        changed[(rbeg + c) / L] = 1;   // benign race: all write 1
+      }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tt = 0;
+      for (int k = 0; k < 16; ++k) tt += wsum[k];
+      base_s += tt;
+    }
+    __syncthreads();
+  }
+  const int n = base_s;
+  const int np = (n + pad - 1) / pad * pad;
+  for (int k = n + threadIdx.x; k < np; k += 1024) rows_out[k] = 0;  // padding rows: computed, never used
+  if (threadIdx.x == 0) { n_out[0] = np; n_out[1] = n; }
+}
+
+// Stage 2: categorical draw from softmax(logits row) over v != mask for the
+// listed rows (dense logits row i belongs to position rows[i]).
+template <typename T>
+__global__ __launch_bounds__(NT) void lazy_race_kernel(
+    const T* __restrict__ logits, int64_t ld, const int32_t* __restrict__ rows,
+    const int32_t* __restrict__ n_rows, uint64_t seed, uint64_t offset,
+    int64_t* __restrict__ x_next, int V, int mask) {
+  __shared__ float smv[4]; __shared__ int smi[4];
+  const int i = blockIdx.x;
+  if (i >= n_rows[1]) return;
+  const T* row = logits + (int64_t)i * ld;
+  const uint64_t G = (uint64_t)((V + 3) >> 2);
+  const uint64_t ctr0 = offset + (uint64_t)i * G;
+  FastRace fr;
+  for (int g = threadIdx.x; g < (int)G; g += NT) {
+    const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)g);
+    const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int v = g * 4 + k;
+      if (v < V && v != mask) fr.put(fast_key<1>(elem<T>::load(row + v), rr[k], 1.f), v);
+    }
+  }
+  ArgMax am; am.v = fr.best; am.i = fr.idx;
+  const int best = block_argmax(am, smv, smi);
+  if (threadIdx.x == 0) x_next[rows[i]] = best;
+}
+
 static bool is16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace mdlm
@@ -923,6 +1024,35 @@ extern "C" int mdlm_d3pm_loss(const float* neg_logp_x0, const int64_t* xt,
   const int64_t n = (int64_t)B * L;
   if (n == 0) return 0;
   d3pm_loss_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ST(stream)>>>(neg_logp_x0, xt, t, T, attn_mask, out, n, L, mask_index);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_lazy_select(const int64_t* x, const float* t, double dt,
+                                uint64_t seed, uint64_t offset, int B, int L,
+                                int mask_index, int pad, int64_t* x_next,
+                                int32_t* rows, int32_t* n_rows, int32_t* changed,
+                                void* stream) {
+  MDLM_CHECK_ARG(x && t && x_next && rows && n_rows && changed, "lazy_select: null pointer");
+  MDLM_CHECK_ARG(B >= 0 && L > 0 && pad > 0 && (int64_t)B * L < (1ll << 31), "lazy_select: bad shape");
+  hipStream_t s = ST(stream);
+  hipError_t e = hipMemsetAsync(changed, 0, sizeof(int32_t) * (size_t)B, s);
+  if (e != hipSuccess) { set_error("lazy_select: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+  lazy_select_kernel<<<1, 1024, 0, s>>>(x, t, (float)dt, seed, offset, B * L, L, mask_index, pad, x_next, rows, n_rows, changed);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_lazy_race(const void* logits, int64_t ld, int dtype,
+                              const int32_t* rows, const int32_t* n_rows,
+                              int max_rows, uint64_t seed, uint64_t offset,
+                              int64_t* x_next, int V, int mask_index, void* stream) {
+  MDLM_CHECK_ARG(logits && rows && n_rows && x_next, "lazy_race: null pointer");
+  MDLM_CHECK_ARG(max_rows >= 0 && V > 0 && ld >= V && mask_index >= 0 && mask_index < V, "lazy_race: bad shape");
+  MDLM_CHECK_ARG(dtype == MDLM_F32 || dtype == MDLM_BF16, "lazy_race: bad dtype");
+  if (max_rows == 0) return 0;
+  if (dtype == MDLM_F32) lazy_race_kernel<float><<<(unsigned)max_rows, NT, 0, ST(stream)>>>((const float*)logits, ld, rows, n_rows, seed, offset, x_next, V, mask_index);
+  else lazy_race_kernel<bf16_t><<<(unsigned)max_rows, NT, 0, ST(stream)>>>((const bf16_t*)logits, ld, rows, n_rows, seed, offset, x_next, V, mask_index);
   MDLM_LAUNCH_CHECK();
   return 0;
 }

@@ -314,13 +314,18 @@ class Diffusion(_Base):
   # ----------------------------------------------------------------- sampling
   def _sampler_state(self, B, Lq):
     st = self._state
-    if st is not None and st['B'] == B and st['L'] == Lq and st['dev'] == self.device:
+    lazy = bool(self.config.sampling.get('lazy_unmask', False))
+    if (st is not None and st['B'] == B and st['L'] == Lq and st['dev'] == self.device
+        and st['lazy'] == lazy):
       return st
     dev = self.device
     i32 = dict(dtype=torch.int32, device=dev)
+    buf = torch.empty(B, Lq, ops.padded_vocab(self.vocab_size),
+                      dtype=torch.bfloat16, device=dev)   # rows 16-byte aligned
     st = dict(
-      B=B, L=Lq, dev=dev,
-      cache=ops.alloc_logits(B, Lq, self.vocab_size, torch.bfloat16, dev),
+      B=B, L=Lq, dev=dev, lazy=lazy,
+      cache=buf[:, :, :self.vocab_size],
+      cache2d=buf.view(B * Lq, -1)[:, :self.vocab_size],
       lse=torch.zeros(B * Lq, dtype=torch.float32, device=dev),
       xa=torch.empty(B, Lq, dtype=torch.int64, device=dev),
       xb=torch.empty(B, Lq, dtype=torch.int64, device=dev),
@@ -330,6 +335,13 @@ class Diffusion(_Base):
       gather=torch.zeros(B * Lq + 256, **i32), scatter=torch.zeros(B * Lq + 256, **i32),
       n_mrows=torch.zeros(1, **i32), fresh=torch.ones(B, **i32),
       zeros=torch.zeros(B, dtype=torch.float32, device=dev))
+    if lazy:
+      if (B * Lq) % 256:
+        raise NotImplementedError('sampling.lazy_unmask needs batch * length % 256 == 0')
+      st.update(
+        hidden=torch.empty(B * Lq, self.backbone.hidden, dtype=torch.float32, device=dev),
+        sel=torch.zeros(B * Lq + 256, **i32), n_sel=torch.zeros(2, **i32),
+        ident=torch.arange(B, **i32), n_all=torch.full((1,), B, **i32))
     self._state = st
     return st
 
@@ -376,6 +388,34 @@ class Diffusion(_Base):
       offset=off, changed=st['changed'], x_next=x_next, fresh=st['fresh'],
       fast_math=bool(self.config.sampling.get('fast_math', False)))
 
+  # ---- opt-in two-stage step (sampling.lazy_unmask=true) ---------------------
+  def _lazy_refresh_hidden(self, st, x):
+    """Backbone blocks for the samples whose tokens changed; their final
+    residual stream goes to the per-sample hidden-state cache (0.2 GB instead of
+    the 6.6 GB logits cache)."""
+    B, Lq = st['B'], st['L']
+    ops.compact_active(st['changed'], st['active'], st['n_active'], st['n_rows'],
+                       Lq, nfe_accum=st['nfe'], fresh=st['fresh'])
+    self.backbone.run(x, st['zeros'], None, sigma_is_zero=True, active=st['active'],
+                      n_active_dev=st['n_active'], n_rows_dev=st['n_rows'],
+                      n_max=B, hidden_out=st['hidden'])
+
+  def _lazy_step(self, st, x, x_next, t_vec, dt):
+    """Same distribution as `_ddpm_caching_update` (diffusion.py:592-610), drawn
+    in two stages: Bernoulli(1 - (t-dt)/t) per masked position, then a
+    categorical draw from p_x0 for the positions that unmask -- the vocabulary
+    projection runs for those rows only.  Not bit-identical to the reference
+    race on a shared uniform tensor; see include/mdlm_hip.h."""
+    B, Lq, V = st['B'], st['L'], self.vocab_size
+    self._lazy_refresh_hidden(st, x)
+    seed, off = self._draw((B * Lq + 3) // 4 + 2)
+    ops.lazy_select(x, t_vec, dt, self.mask_index, x_next, st['sel'], st['n_sel'],
+                    st['changed'], seed=seed, offset=off)
+    self.backbone.project_rows(st['hidden'], st['sel'], st['n_sel'], st['cache2d'], Lq)
+    seed, off = self._draw(B * Lq * ((V + 3) // 4))
+    ops.lazy_race(st['cache2d'], st['sel'], st['n_sel'], x_next, V, self.mask_index,
+                  seed=seed, offset=off)
+
   @torch.no_grad()
   def _sample(self, num_steps=None, eps=1e-5):
     """Generate samples from the model (diffusion.py:657-698)."""
@@ -401,11 +441,27 @@ class Diffusion(_Base):
     st['nfe'].zero_()
     # t = timesteps[i] * ones(B, 1)  (diffusion.py:675-676), all steps at once
     t_all = timesteps[:, None].expand(num_steps + 1, B).contiguous()
+    lazy = bool(self.config.sampling.get('lazy_unmask', False))
+    if lazy and self.time_conditioning:
+      raise NotImplementedError('sampling.lazy_unmask needs time_conditioning=False '
+                                '(the hidden-state cache is sigma-independent)')
     for i in range(num_steps):
-      sigma = self.noise(t_all[i])[0] if self.time_conditioning else None
-      self._fused_step(st, x, x_next, t_all[i], dt, sigma)
+      if lazy:
+        self._lazy_step(st, x, x_next, t_all[i], dt)
+      else:
+        sigma = self.noise(t_all[i])[0] if self.time_conditioning else None
+        self._fused_step(st, x, x_next, t_all[i], dt, sigma)
       x, x_next = x_next, x
-    if self.config.sampling.noise_removal:
+    if self.config.sampling.noise_removal and lazy:
+      # argmax over the positions still masked: project exactly those rows
+      self._lazy_refresh_hidden(st, x)
+      ops.masked_row_map(x, st['ident'], st['n_all'], Lq, self.mask_index,
+                         st['gather'], st['scatter'], st['n_mrows'])
+      self.backbone.project_rows(st['hidden'], st['gather'], st['n_mrows'],
+                                 st['cache2d'], Lq, out_row_map=st['scatter'])
+      ops.subs_argmax(st['cache'], x, self.mask_index, out=x_next)
+      x = x_next
+    elif self.config.sampling.noise_removal:
       # forward(x, sigma(t_last)).argmax(-1)  (diffusion.py:690-697)
       sigma = self.noise(t_all[-1])[0] if self.time_conditioning else None
       self._refresh_cache(st, x, sigma)

@@ -226,7 +226,8 @@ class DIT(nn.Module):
     ev[tag].append((e0, e1, rows, flops_per_row))
 
   def run(self, indices, sigma, logits_out, sigma_is_zero=False, active=None,
-          n_active_dev=None, n_rows_dev=None, n_max=None, row_map=None):
+          n_active_dev=None, n_rows_dev=None, n_max=None, row_map=None,
+          hidden_out=None):
     """Run the backbone.  `indices` (B, L) int64.  `logits_out`: (B, L, V)
     bf16/fp32 view (padded leading dimension allowed).  If `active` (int32
     device list) is given, only the listed samples are evaluated (compacted
@@ -234,7 +235,11 @@ class DIT(nn.Module):
     logits_out[active[i]]; n_active_dev / n_rows_dev are device counters and
     n_max the launch bound.  `row_map = (gather, scatter, n_dev)` from
     `ops.masked_row_map` restricts the final LayerNorm + vocabulary projection
-    to the masked rows (the only rows whose logits are ever read)."""
+    to the masked rows (the only rows whose logits are ever read).
+    `hidden_out` (B*L, D) fp32: stop after the last block and write the
+    residual stream of the evaluated samples to their rows of this per-sample
+    cache instead of projecting to the vocabulary (`project_rows` does that
+    later for the rows that need it)."""
     B, L = indices.shape
     p = self._prepare(L)
     D, H = self.hidden, self.n_heads
@@ -277,6 +282,9 @@ class DIT(nn.Module):
         mh, bp['fc2'], x, EPI_GATE_RESIDUAL, bias=bp['b2'],
         gate=mod[:, 5 * D:6 * D], residual=x, rows_per_mod=L,
         n_mod=n_mod, mod_ld=ld6, m_rows_dev=n_rows_dev, M=M))
+    if hidden_out is not None:
+      ops.scatter_rows_f32(x, hidden_out, active, L, n_rows_dev=n_rows_dev)
+      return None
     fm = mods[-1]
     assert logits_out.shape[-1] == self.vocab_size
     V = self.vocab_size
@@ -296,6 +304,25 @@ class DIT(nn.Module):
         h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
         rows_per_mod=L, m_rows_dev=n_rows_dev, out_sample_map=active,
         ldc=logits_out.stride(-2), M=M))
+    return logits_out
+
+  def project_rows(self, hidden, gather, n_rows_dev, logits_out, L,
+                   out_row_map=None):
+    """Output layer (dit.py:317-321, sigma = 0 conditioning) for the listed rows
+    of a per-sample hidden-state cache: LN + modulate gathers `hidden[gather[i]]`
+    into dense rows, the vocabulary GEMM writes logits row i to `logits_out[i]`
+    (or to row `out_row_map[i]`).  n_rows_dev: device count, a multiple of 256."""
+    p = self._prepare(L)
+    D, V = self.hidden, self.vocab_size
+    mods, n_mod = self.conditioning(p, None, True)
+    fm = mods[-1]
+    M = hidden.shape[0]
+    h = self._workspace(M)['h'][:M]
+    ops.ln_modulate(hidden, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod,
+                    2 * D, n_rows_dev=n_rows_dev, row_gather=gather, rows=M)
+    ops.gemm_bf16(h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
+                  m_rows_dev=n_rows_dev, out_row_map=out_row_map,
+                  ldc=logits_out.stride(-2), M=M)
     return logits_out
 
   def forward(self, indices, sigma, out=None, out_dtype=torch.bfloat16):

@@ -192,6 +192,37 @@ def d3pm_loss(neg_logp_x0, xt, t, T, mask_index, attn_mask=None):
   return out
 
 
+def lazy_select(x, t, dt, mask_index, x_next, rows, n_rows, changed, seed=0,
+                offset=0, pad=256):
+  """Stage 1 of the opt-in two-stage step (see include/mdlm_hip.h)."""
+  x = _dev(x, 'x', torch.int64).contiguous()
+  B, L = x.shape
+  tt = _t_vec(t, B)
+  call('mdlm_lazy_select', x.data_ptr(), tt.data_ptr(), float(dt), int(seed),
+       int(offset), B, L, int(mask_index), int(pad), x_next.data_ptr(),
+       rows.data_ptr(), n_rows.data_ptr(), changed.data_ptr(), _stream())
+  return x_next
+
+
+def lazy_race(logits, rows, n_rows, x_next, V, mask_index, seed=0, offset=0):
+  """Stage 2: logits (max_rows, >=V) dense rows of the listed positions."""
+  _dev(logits, 'logits')
+  assert logits.dim() == 2 and logits.stride(1) == 1
+  call('mdlm_lazy_race', logits.data_ptr(), logits.stride(0), _DT[logits.dtype],
+       rows.data_ptr(), n_rows.data_ptr(), logits.shape[0], int(seed),
+       int(offset), x_next.data_ptr(), int(V), int(mask_index), _stream())
+  return x_next
+
+
+def scatter_rows_f32(src, dst, sample_map, L, n_rows_dev=None):
+  src = _dev(src, 'src', torch.float32)
+  dst = _dev(dst, 'dst', torch.float32)
+  assert src.is_contiguous() and dst.is_contiguous() and src.shape[1] == dst.shape[1]
+  call('mdlm_scatter_rows_f32', src.data_ptr(), dst.data_ptr(), _p(sample_map),
+       int(L), src.shape[1], src.shape[0], _p(n_rows_dev), _stream())
+  return dst
+
+
 def philox_uniform(rows, V, seed, offset=0, device='cuda'):
   out = torch.empty(rows, V, dtype=torch.float32, device=device)
   call('mdlm_philox_uniform', out.data_ptr(), rows, V, int(seed), int(offset),

@@ -358,3 +358,112 @@ def test_full_size_rows_properties(ops):
   assert (am != mask).all()
   am2 = ops.subs_argmax(logits, am, mask)
   assert torch.equal(am2, am)
+
+
+def test_lazy_unmask_kernels_statistics(ops):
+  """Opt-in two-stage step (no reference counterpart; distribution-identical to
+  diffusion.py:592-610): stage 1 unmasks with probability dt/t, never touches
+  unmasked positions and flags the samples it changed; stage 2 draws tokens
+  from softmax(logits) over v != mask."""
+  B, L, Vv, mask = 64, 1024, 24, 23
+  torch.manual_seed(0)
+  x = torch.randint(0, Vv - 1, (B, L)); x[torch.rand(B, L) < 0.8] = mask
+  x[5] = 3                                   # a sample with nothing masked
+  t = torch.full((B,), 0.5); dt = 0.1       # P(unmask) = 0.2
+  xc = x.cuda()
+  x_next = torch.empty_like(xc)
+  rows = torch.zeros(B * L + 256, dtype=torch.int32, device='cuda')
+  n = torch.zeros(2, dtype=torch.int32, device='cuda')
+  changed = torch.zeros(B, dtype=torch.int32, device='cuda')
+  ops.lazy_select(xc, t.cuda(), dt, mask, x_next, rows, n, changed, seed=11, offset=5)
+  n_pad, n_sel = n.tolist()
+  assert n_pad % 256 == 0 and 0 <= n_pad - n_sel < 256
+  assert torch.equal(x_next, xc)
+  sel = rows[:n_sel].long().cpu()
+  assert (sel[1:] > sel[:-1]).all()                      # ascending, unique
+  assert (x.view(-1)[sel] == mask).all()                 # only masked positions
+  n_masked = int((x == mask).sum())
+  p = 0.2
+  assert abs(n_sel - p * n_masked) < 5 * math.sqrt(n_masked * p * (1 - p))
+  exp_changed = torch.zeros(B, dtype=torch.int32); exp_changed[torch.unique(sel // L)] = 1
+  assert torch.equal(changed.cpu(), exp_changed) and changed[5].item() == 0
+  # t <= dt: everything unmasks
+  ops.lazy_select(xc, torch.full((B,), 0.1).cuda(), 0.1, mask, x_next, rows, n, changed, seed=1)
+  assert n.tolist()[1] == n_masked
+  # stage 2: 32768 rows sharing one logits row -> empirical token distribution
+  R = 32768
+  lg = torch.randn(Vv) * 1.5
+  logits = lg.repeat(R, 1).to(torch.bfloat16).cuda()
+  rows2 = torch.arange(R, dtype=torch.int32, device='cuda')
+  n2 = torch.tensor([R, R], dtype=torch.int32, device='cuda')
+  out = torch.full((R,), -1, dtype=torch.int64, device='cuda')
+  ops.lazy_race(logits, rows2, n2, out, Vv, mask, seed=3, offset=0)
+  cnt = torch.bincount(out.cpu(), minlength=Vv).double()
+  assert cnt[mask] == 0 and cnt.sum() == R
+  pr = torch.softmax(logits[0, :mask].float().cpu().double(), -1)
+  chi2 = (((cnt[:mask] - R * pr) ** 2) / (R * pr)).sum().item()
+  assert chi2 < 60.0        # 22 dof: P(chi2 > 60) ~ 2e-5
+
+
+def test_lazy_unmask_sampler(ops):
+  """End to end: no mask left, hidden-state cache NFE matches the exact
+  sampler's on average, unmask times follow the same law (mean step ~ T/2)."""
+  model, cfg, p = make_model(['sampling.lazy_unmask=true', 'loader.eval_batch_size=4',
+                              'sampling.fast_math=true'])
+  model.seed_rng(5)
+  out = model._sample(num_steps=32).cpu()
+  assert out.shape == (4, cfg.model.length) and (out != MASK).all()
+  nfe_lazy = int(model.last_nfe.item())
+  exact, _, _ = make_model(['loader.eval_batch_size=4', 'sampling.fast_math=true'])
+  exact.seed_rng(5)
+  out2 = exact._sample(num_steps=32).cpu()
+  nfe_exact = int(exact.last_nfe.item())
+  assert abs(nfe_lazy - nfe_exact) <= 0.25 * nfe_exact
+  # token marginals of the two samplers agree in distribution (same model):
+  # compare the mean token id as a crude two-sample statistic
+  a, b = out.float().mean().item(), out2.float().mean().item()
+  assert abs(a - b) < 0.25 * V
+
+
+def test_lazy_step_matches_reference_distribution(ops):
+  """One `_lazy_step` from a fixed state, repeated: the unmask rate is dt/t and
+  the drawn tokens follow p_x0 OF THEIR OWN POSITION (checks the row gather /
+  scatter of the hidden-state cache): the mean of log p_x0[r, x_next[r]] over
+  unmasked positions must equal its expectation sum_v p log p."""
+  model, cfg, p = make_model(['sampling.lazy_unmask=true', 'loader.eval_batch_size=4',
+                              'sampling.fast_math=true'])
+  B, L = 4, cfg.model.length
+  torch.manual_seed(8)
+  x = torch.randint(0, V - 1, (B, L)); x[torch.rand(B, L) < 0.6] = MASK
+  xc = x.cuda()
+  logp = model.forward(xc, torch.zeros(B, device='cuda')).float().cpu()   # SUBS log-probs
+  masked = (x == MASK)
+  pm = logp[masked][:, :MASK].double()                 # (n_masked, V-1)
+  ent = (pm.exp() * pm).sum(-1)                        # E[log p(token)] per position
+  var = (pm.exp() * pm * pm).sum(-1) - ent ** 2
+  st = model._sampler_state(B, L)
+  t = torch.full((B,), 0.5, device='cuda'); dt = 0.25   # P(unmask) = 0.5
+  model.seed_rng(99)
+  n_un, s_lp, e_lp, v_lp = 0, 0.0, 0.0, 0.0
+  reps = 64
+  for _ in range(reps):
+    st['changed'].fill_(1)                             # every sample refreshes its hidden state
+    xn = torch.empty_like(xc)
+    model._lazy_step(st, xc, xn, t, dt)
+    xn = xn.cpu()
+    assert torch.equal(xn[~masked], x[~masked])        # carry-over
+    un = masked & (xn != MASK)
+    n_un += int(un.sum())
+    s_lp += logp[un].gather(-1, xn[un][:, None]).double().sum().item()
+    sel = un[masked]
+    e_lp += ent[sel].sum().item(); v_lp += var[sel].sum().item()
+  # row mapping, deterministically: dense logits row i of the last step == the
+  # full forward's logits at position sel[i] (row-independent kernels: bit-exact)
+  full = model.backbone(xc, torch.zeros(B, device='cuda')).view(B * L, -1)
+  n_pad, n_sel = st['n_sel'].tolist()
+  assert n_sel > 0
+  sel = st['sel'][:n_sel].long()
+  assert torch.equal(st['cache2d'][:n_sel], full[sel])
+  n_m = int(masked.sum()) * reps
+  assert abs(n_un - 0.5 * n_m) < 5 * math.sqrt(n_m * 0.25)
+  assert abs(s_lp - e_lp) < 5 * math.sqrt(v_lp) + 1e-6 * abs(e_lp) + 0.05 * n_un * 2e-2
