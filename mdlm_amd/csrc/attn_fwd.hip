@@ -150,6 +150,10 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_kernel(
         for (int t = 0; t < QT; ++t)
           sacc[t][kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
             kf[kt2][ks], qf[t][ks], ks == 0 ? zero16 : sacc[t][kt2], 0, 0, 0);
+    // keep all sixteen fragment reads ahead of the MFMAs (hipcc otherwise sinks
+    // each K read to just before its MFMA pair: read -> wait -> 2 MFMAs)
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * QT, 0);
     // ---- online softmax (per query column; keys in-lane + other half) ----
     bf16x8 pf[QT][4];
 #pragma unroll
