@@ -73,7 +73,9 @@ struct Philox {
       const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
       unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
       unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
-      unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+      // three-input xor in one v_bitop3_b32 (truth table 0x96)
+      unsigned n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
+      unsigned n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
       c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
       k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
