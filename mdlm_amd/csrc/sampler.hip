@@ -810,6 +810,7 @@ extern "C" int mdlm_subs_logprobs(const void* logits, int64_t ld_in, int dtype_i
                                   const int64_t* xt, void* out, int64_t ld_out,
                                   int dtype_out, int64_t rows, int V,
                                   int mask_index, int as_probs, void* stream) {
+  if (rows == 0) return 0;  // empty batch: nothing to do (empty tensors carry null pointers)
   MDLM_CHECK_ARG(logits && xt && out, "subs_logprobs: null pointer");
   MDLM_CHECK_ARG(rows >= 0 && rows < (1ll << 31) && V > 0 && ld_in >= V && ld_out >= V,
                  "subs_logprobs: bad shape rows=%lld V=%d ld_in=%lld ld_out=%lld",
@@ -845,6 +846,7 @@ extern "C" int mdlm_subs_row_lse(const void* logits, int64_t ld, int dtype,
                                  int V, int mask_index,
                                  const int32_t* sample_map, int L,
                                  const int32_t* n_rows_dev, void* stream) {
+  if (rows == 0) return 0;
   MDLM_CHECK_ARG(logits && xt && lse, "subs_row_lse: null pointer");
   MDLM_CHECK_ARG(rows >= 0 && rows < (1ll << 31) && V > 0 && ld >= V, "subs_row_lse: bad shape");
   MDLM_CHECK_ARG(mask_index >= 0 && mask_index < V, "subs_row_lse: mask_index out of range");
@@ -860,6 +862,7 @@ extern "C" int mdlm_subs_row_lse(const void* logits, int64_t ld, int dtype,
 extern "C" int mdlm_subs_argmax(const void* logits, int64_t ld, int dtype,
                                 const int64_t* xt, int64_t* out, int64_t rows,
                                 int V, int mask_index, void* stream) {
+  if (rows == 0) return 0;
   MDLM_CHECK_ARG(logits && xt && out, "subs_argmax: null pointer");
   MDLM_CHECK_ARG(rows >= 0 && rows < (1ll << 31) && V > 0 && ld >= V, "subs_argmax: bad shape");
   MDLM_CHECK_ARG(mask_index >= 0 && mask_index < V, "subs_argmax: mask_index out of range");
@@ -880,6 +883,7 @@ static int launch_update(const void* src, int64_t ld, int dtype, float* lse,
                          int64_t* x_next, int32_t* changed, int B, int L, int V,
                          int mask_index, int fast_math, void* stream) {
   const char* nm = q_scale ? "subs_race_update" : SRC ? "subs_ddpm_update" : "ddpm_cache_update";
+  if (B == 0) return 0;
   MDLM_CHECK_ARG(src && x && (t || q_scale) && x_next, "%s: null pointer", nm);
   MDLM_CHECK_ARG(!q_scale == !q_mask, "%s: q_scale and q_mask go together", nm);
   MDLM_CHECK_ARG(SRC == 0 || lse, "%s: lse is required", nm);
@@ -958,6 +962,7 @@ extern "C" int mdlm_philox_uniform(float* out, int64_t rows, int V, uint64_t see
 extern "C" int mdlm_q_xt(const int64_t* x0, const float* move_chance,
                          const float* u, uint64_t seed, uint64_t offset,
                          int64_t* xt, int B, int L, int mask_index, void* stream) {
+  if (B == 0) return 0;
   MDLM_CHECK_ARG(x0 && move_chance && xt, "q_xt: null pointer");
   MDLM_CHECK_ARG(B >= 0 && L > 0, "q_xt: bad shape");
   const int64_t n = (int64_t)B * L;
@@ -972,6 +977,7 @@ extern "C" int mdlm_subs_nll(const void* logits, int64_t ld, int dtype,
                              const float* weight, const float* attn_mask,
                              float* nll, int B, int L, int V, int mask_index,
                              void* stream) {
+  if (B == 0) return 0;
   MDLM_CHECK_ARG(logits && xt && x0 && weight && nll, "subs_nll: null pointer");
   MDLM_CHECK_ARG(B >= 0 && L > 0 && V > 0 && ld >= V && (int64_t)B * L < (1ll << 31), "subs_nll: bad shape");
   MDLM_CHECK_ARG(mask_index >= 0 && mask_index < V, "subs_nll: mask_index out of range");
@@ -1019,6 +1025,7 @@ extern "C" int mdlm_d3pm_loss(const float* neg_logp_x0, const int64_t* xt,
                               const float* t, int T, const float* attn_mask,
                               float* out, int B, int L, int mask_index,
                               void* stream) {
+  if (B == 0) return 0;
   MDLM_CHECK_ARG(neg_logp_x0 && xt && t && out, "d3pm_loss: null pointer");
   MDLM_CHECK_ARG(B >= 0 && L > 0 && T > 0, "d3pm_loss: bad shape / T");
   const int64_t n = (int64_t)B * L;

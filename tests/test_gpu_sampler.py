@@ -342,3 +342,47 @@ def test_errors_are_loud(ops):
     ops.subs_logprobs(x, torch.zeros(2, 4, dtype=torch.int64), 7)  # CPU tensor
   with pytest.raises(RuntimeError):
     ops.subs_logprobs(x.cuda(), torch.zeros(2, 4, dtype=torch.int64).cuda(), 8)
+
+
+def test_edge_shapes(ops):
+  """Empty batches, one row, tiny unaligned vocabularies, nothing / everything
+  masked: every entry point must match the oracle (or be a no-op)."""
+  # empty batch: no launch, no error
+  e = torch.zeros(0, 8, 16, device='cuda')
+  ex = torch.zeros(0, 8, dtype=torch.int64, device='cuda')
+  assert ops.subs_logprobs(e, ex, 15).shape == (0, 8, 16)
+  assert ops.subs_argmax(e, ex, 15).shape == (0, 8)
+  assert ops.q_xt(ex, torch.zeros(0, device='cuda'), 15).shape == (0, 8)
+  assert ops.ddpm_cache_update(e, ex, torch.zeros(0, device='cuda'), 0.1, 15).shape == (0, 8)
+  for (B, L, Vv) in [(1, 1, 5), (2, 3, 7), (1, 5, 130), (3, 2, 1000)]:
+    mask = Vv - 1
+    torch.manual_seed(B * 100 + Vv)
+    for frac in (0.0, 0.5, 1.0):
+      logits = torch.randn(B, L, Vv) * 3
+      x = torch.randint(0, Vv - 1, (B, L))
+      x[torch.rand(B, L) < frac] = mask
+      if frac == 1.0:
+        x[:] = mask
+      ref = orc.subs_parameterization(logits.clone(), x, mask)
+      got = ops.subs_logprobs(logits.cuda(), x.cuda(), mask).cpu()
+      torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+      assert torch.equal(ops.subs_argmax(logits.cuda(), x.cuda(), mask).cpu(), ref.argmax(-1))
+      p = ref.exp()
+      t = torch.rand(B, 1) * 0.8 + 0.2
+      u = torch.rand(B, L, Vv)
+      _, xn_ref = orc.ddpm_caching_update(None, x, t, 0.1, u, mask, p_x0=p.clone())
+      xn = ops.ddpm_cache_update(p.cuda(), x.cuda(), t.cuda(), 0.1, mask, u=u.cuda()).cpu()
+      assert torch.equal(xn, xn_ref), (B, L, Vv, frac)
+      # fused from logits + generic race with the ddpm_cache weights: same tokens
+      lse = torch.zeros(B * L, device='cuda')
+      fresh = torch.ones(B, dtype=torch.int32, device='cuda')
+      xn2 = ops.subs_ddpm_update(logits.cuda(), lse, x.cuda(), t.cuda(), 0.1, mask, u=u.cuda(), fresh=fresh).cpu()
+      tt = t.squeeze(-1)
+      xn3 = ops.subs_race_update(logits.cuda(), lse, x.cuda(), (tt - (tt - 0.1)).cuda(), (tt - 0.1).cuda(),
+                                 mask, u=u.cuda(), fresh=fresh).cpu()
+      assert torch.equal(xn2, xn3)
+      assert torch.equal(xn2[x != mask], x[x != mask])
+      # q_xt and the NLL on the same tiny shapes
+      mc = torch.rand(B, 1)
+      uq = torch.rand(B, L)
+      assert torch.equal(ops.q_xt(x.cuda(), mc.cuda(), mask, u=uq.cuda()).cpu(), orc.q_xt(x, mc, uq, mask))
