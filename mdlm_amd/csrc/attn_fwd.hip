@@ -234,6 +234,7 @@ using namespace mdlm;
 extern "C" int mdlm_attn_fwd(const void* q, const void* k, const void* vt,
                              void* out, int n_seq, int H, int L,
                              const int32_t* n_seq_dev, void* stream) {
+  if (n_seq == 0) return 0;
   MDLM_CHECK_ARG(q && k && vt && out, "attn_fwd: null pointer");
   MDLM_CHECK_ARG(n_seq >= 0 && H > 0 && L > 0 && L % QB == 0, "attn_fwd: L=%d must be a multiple of %d", L, QB);
   MDLM_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) == 0, "attn_fwd: buffers must be 16-byte aligned");

@@ -143,6 +143,7 @@ extern "C" int mdlm_embed_rows(const float* table, const int64_t* idx,
                                const int32_t* sample_map, int L, float* out,
                                int64_t n_rows, int D, int vocab,
                                const int32_t* n_rows_dev, void* stream) {
+  if (n_rows == 0) return 0;
   MDLM_CHECK_ARG(table && idx && out, "embed_rows: null pointer");
   MDLM_CHECK_ARG(n_rows >= 0 && D > 0 && D % 4 == 0 && vocab > 0 && L > 0, "embed_rows: bad shape (D %% 4 must be 0)");
   if (n_rows == 0) return 0;
@@ -152,8 +153,8 @@ extern "C" int mdlm_embed_rows(const float* table, const int64_t* idx,
 }
 
 extern "C" int mdlm_timestep_embedding(const float* t, float* out, int B, int dim, void* stream) {
-  MDLM_CHECK_ARG(t && out && B >= 0 && dim >= 2, "timestep_embedding: bad args");
   if (B == 0) return 0;
+  MDLM_CHECK_ARG(t && out && B >= 0 && dim >= 2, "timestep_embedding: bad args");
   const int n = B * (dim / 2);
   timestep_embedding_kernel<<<(n + 255) / 256, 256, 0, ST(stream)>>>(t, out, B, dim);
   MDLM_LAUNCH_CHECK();
@@ -163,6 +164,7 @@ extern "C" int mdlm_timestep_embedding(const float* t, float* out, int B, int di
 extern "C" int mdlm_linear_f32(const float* in, const float* W, const float* bias,
                                float* out, int B, int N, int K, int act_in,
                                int act_out, void* stream) {
+  if (B == 0) return 0;
   MDLM_CHECK_ARG(in && W && out && B >= 0 && N > 0 && K > 0, "linear_f32: bad args");
   MDLM_CHECK_ARG((act_in == 0 || act_in == 1) && (act_out == 0 || act_out == 1), "linear_f32: bad activation");
   if (B == 0) return 0;
@@ -178,6 +180,7 @@ extern "C" int mdlm_ln_modulate(const float* x, const float* ln_w,
                                 int64_t rows_per_mod, int n_mod, int64_t mod_ld,
                                 const int32_t* row_gather,
                                 const int32_t* n_rows_dev, void* stream) {
+  if (rows == 0) return 0;
   MDLM_CHECK_ARG(x && ln_w && shift && scale && out_bf16, "ln_modulate: null pointer");
   MDLM_CHECK_ARG(rows >= 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_NV, "ln_modulate: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_NV);
   MDLM_CHECK_ARG(rows_per_mod > 0 && n_mod > 0 && mod_ld % 4 == 0 && (n_mod == 1 || mod_ld >= D), "ln_modulate: bad modulation shape");

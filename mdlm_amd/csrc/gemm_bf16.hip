@@ -600,6 +600,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
                               int n_heads, const int32_t* m_rows_dev,
                               const int32_t* out_sample_map,
                               const int32_t* out_row_map, void* stream) {
+  if (M == 0) return 0;
   MDLM_CHECK_ARG(A && W && C, "gemm_bf16: null pointer");
   MDLM_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_bf16: bad shape");
   MDLM_CHECK_ARG(M % 128 == 0, "gemm_bf16: M=%lld must be a multiple of 128", (long long)M);

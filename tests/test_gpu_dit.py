@@ -261,6 +261,9 @@ def test_dit_forward_vs_oracle(ops, shape):
     lp = torch.log_softmax(o, -1); lr = torch.log_softmax(ref, -1)
     assert (lp - lr).abs().max().item() < 6e-2
     assert (lp - lr).abs().mean().item() < 1e-2
+  # empty batch: every kernel entry point is a no-op
+  e = model(torch.zeros(0, L, dtype=torch.int64).cuda(), torch.zeros(0).cuda())
+  assert e.shape == (0, L, V)
   # constant-conditioning shortcut (sigma zeroed) == general path
   out0 = model.run(idx.cuda(), torch.zeros(B).cuda(),
                    ops.alloc_logits(B, L, V), sigma_is_zero=True)
