@@ -467,3 +467,47 @@ def test_lazy_step_matches_reference_distribution(ops):
   n_m = int(masked.sum()) * reps
   assert abs(n_un - 0.5 * n_m) < 5 * math.sqrt(n_m * 0.25)
   assert abs(s_lp - e_lp) < 5 * math.sqrt(v_lp) + 1e-6 * abs(e_lp) + 0.05 * n_un * 2e-2
+
+
+def test_checkpoint_ingestion(ops, tmp_path):
+  """Reference Lightning `.ckpt` layout (state_dict['backbone.*'] + ckpt['ema']
+  shadow params in backbone.parameters() order, diffusion.py:168-181,
+  ema.py:79-97) and a plain safetensors backbone file, through the loaders
+  `main.py` uses (weights_only=True / safetensors: nothing from the file is
+  executed).  Sampling must then run on the EMA weights, as
+  `restore_model_and_sample` does in the reference (700-719)."""
+  import main as cli
+  from safetensors.torch import save_file
+  model, cfg, p = make_model(['training.ema=0.9999'])
+  src, _, _ = make_model(seed=9)
+  sd = {f'backbone.{k}': v.detach().cpu().clone() for k, v in src.backbone.state_dict().items()}
+  shadow = [q.detach().cpu().clone() * 0.5 for q in src.backbone.parameters()]
+  ckpt = {'state_dict': sd, 'ema': {'decay': 0.9999, 'num_updates': 10, 'shadow_params': shadow}}
+  path = str(tmp_path / 'ref.ckpt')
+  torch.save(ckpt, path)
+  from mdlm_amd.config import load_config
+  from mdlm_amd.diffusion import Diffusion
+  from mdlm_amd.tokenizer import SyntheticTokenizer
+  m2 = Diffusion(load_config(['model=tiny', 'loader.eval_batch_size=4', 'training.ema=0.9999']),
+                 SyntheticTokenizer(vocab_size=V - 1, eos_token_id=7)).cuda()
+  cli._load_backbone_weights(m2, path)
+  for (k, a), b in zip(m2.backbone.state_dict().items(), src.backbone.state_dict().values()):
+    assert torch.equal(a.cpu(), b.cpu()), k
+  assert m2.ema is not None
+  for a, b in zip(m2.ema.shadow_params, shadow):
+    assert torch.equal(a.cpu(), b)
+  # forward uses the raw weights; sampling swaps the EMA weights in and back out
+  x = torch.randint(0, V - 1, (4, cfg.model.length)).cuda()
+  before = m2.backbone(x, torch.zeros(4).cuda()).clone()
+  out = m2.restore_model_and_sample(num_steps=8)
+  assert out.shape == (4, cfg.model.length) and (out != MASK).all()
+  assert torch.equal(m2.backbone(x, torch.zeros(4).cuda()), before)
+  for a, b in zip(m2.backbone.parameters(), src.backbone.parameters()):
+    assert torch.equal(a, b)
+  # safetensors with bare backbone keys
+  st_path = str(tmp_path / 'bb.safetensors')
+  save_file({k: v.detach().cpu().contiguous() for k, v in src.backbone.state_dict().items()}, st_path)
+  m3 = Diffusion(load_config(['model=tiny', 'loader.eval_batch_size=4']),
+                 SyntheticTokenizer(vocab_size=V - 1, eos_token_id=7)).cuda()
+  cli._load_backbone_weights(m3, st_path)
+  assert torch.equal(m3.backbone(x, torch.zeros(4).cuda()), before)
