@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmdlm_hip.so')
+# MDLM_HIP_LIB: another build of the same library (same-box A/B measurements)
+LIB_PATH = os.environ.get('MDLM_HIP_LIB') or os.path.join(_HERE, 'libmdlm_hip.so')
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_BIAS_GELU, EPI_GATE_RESIDUAL, EPI_QKV_ROTARY = 0, 1, 2, 3
