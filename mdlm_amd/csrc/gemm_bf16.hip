@@ -228,6 +228,19 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
     };
     if (ec.ok) {
       if constexpr (BF16_OUT) {
+        // destination rows first (scatter list entries are loads: all in
+        // flight together, not one load -> wait -> store per row group)
+        int64_t drs[MS * 2];
+        bool mapped = false;
+        if constexpr (EPI == MDLM_EPI_STORE) mapped = g.out_row_map != nullptr;
+        if (mapped) {   // one wave-uniform branch around all the loads
+          const int32_t* mp = g.out_row_map + grow0 + (lane >> 3);
+#pragma unroll
+          for (int it = 0; it < MS * 2; ++it) drs[it] = (int64_t)mp[it * 8];
+        } else {
+#pragma unroll
+          for (int it = 0; it < MS * 2; ++it) drs[it] = orow0 + it * 8 + (lane >> 3);
+        }
         // registers -> (bias, GELU) -> packed bf16 -> swizzled LDS tile [MS*16][64]
 #pragma unroll
         for (int m = 0; m < MS; ++m) {
@@ -246,7 +259,7 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
         for (int it = 0; it < MS * 2; ++it) {
           const int row = it * 8 + (lane >> 3), ch = lane & 7;
           const uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((ch ^ (row & 7)) * 16));
-          const int64_t dr = dst_row(row);
+          const int64_t dr = drs[it];
           if (dr >= 0) store16<true>(Cp0 + dr * g.ldc + ch * 8, v, g.dbg);
         }
       } else {
