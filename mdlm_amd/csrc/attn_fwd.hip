@@ -210,20 +210,35 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_kernel(
   }
 
   // ---- normalise and store O[q, head*64 + d] ------------------------------
+  // A lane holds 4 consecutive d of its query row in 8 places: stored straight
+  // from registers that is sixteen 8-byte stores per tile, 16 bytes per row per
+  // instruction.  The K/V stages are free now (every wave passed the last
+  // barrier), so each wave transposes its [32 q][64 d] bf16 tile through 4 KiB
+  // of LDS (16-byte chunk swizzled by row & 7) and writes whole 128-byte rows.
+  char* ot = smem + wid * (QT * 4096);
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32);
     const float inv = 1.f / l_tot;
-    bf16_t* op = out + ((int64_t)seq * L + q0 + t * 32 + r) * ((int64_t)H * HD) + head * HD;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const int d = dt * 32 + 8 * g4 + 4 * hh;
-        *reinterpret_cast<uint2*>(op + d) = make_uint2(
+        const int c16 = dt * 4 + g4;           // 16-byte chunk: d = 8*c16 + 4*hh + (0..3)
+        *reinterpret_cast<uint2*>(ot + t * 4096 + r * 128 + ((c16 ^ (r & 7)) * 16) + hh * 8) = make_uint2(
           pack_bf16x2(oacc[t][dt][4 * g4 + 0] * inv, oacc[t][dt][4 * g4 + 1] * inv),
           pack_bf16x2(oacc[t][dt][4 * g4 + 2] * inv, oacc[t][dt][4 * g4 + 3] * inv));
       }
+  }
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    bf16_t* op = out + ((int64_t)seq * L + q0 + t * 32) * ((int64_t)H * HD) + head * HD;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(ot + t * 4096 + row * 128 + ((ch ^ (row & 7)) * 16));
+      *reinterpret_cast<uint4*>(op + (int64_t)row * ((int64_t)H * HD) + ch * 8) = v;
+    }
   }
 }
 
