@@ -47,7 +47,14 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_kernel(
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE];  // K0 K1 V0 V1
   constexpr int QBQ = QB * QT;           // query rows per workgroup
   const int qblocks = L / QBQ;
-  const int bid = blockIdx.x;
+  // XCD-aware mapping: workgroup ids go round-robin over the 8 XCDs (private
+  // L2s), so the query blocks of one (sequence, head) -- which share its K and
+  // V^T -- are given ids of the same residue mod 8 when the grid allows it.
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0 && ((gridDim.x >> 3) % qblocks) == 0) {
+    const int xcd = bid & 7, j = bid >> 3;
+    bid = ((j / qblocks) * 8 + xcd) * qblocks + (j % qblocks);
+  }
   const int qb = bid % qblocks;
   const int bh = bid / qblocks;        // seq * H + head
   const int seq = bh / H, head = bh - seq * H;
