@@ -150,6 +150,16 @@ int mdlm_lazy_race(const void* logits, int64_t ld, int dtype, const int32_t* row
                    const int32_t* n_rows, int max_rows, uint64_t seed,
                    uint64_t offset, int64_t* x_next, int V, int mask_index,
                    void* stream);
+/* x_dst[i] = x_src[gather[i]] (fp32 rows) and a_dst[i] = a_src[gather[i]] (bf16
+ * rows) for i < *n_rows_dev, D elements each.  Only the masked positions' logits
+ * are ever read (diffusion.py:270-277, 609-610), so after the LAST block's
+ * attention (dit.py:265-275) everything that remains -- out-projection, MLP,
+ * final layer (dit.py:277-288, 317-321) -- is row-wise and runs on those rows
+ * alone, packed densely by this gather. */
+int mdlm_gather_rows(const float* x_src, float* x_dst, const void* a_src,
+                     void* a_dst, const int32_t* gather, int D, int64_t n_rows,
+                     const int32_t* n_rows_dev, void* stream);
+
 /* dst[sample_map[r / L] * L + r % L] = src[r] for r < *n_rows_dev (fp32 rows of
  * D elements): writes the residual stream of the compacted active samples back
  * to a per-sample hidden-state cache (lazy sampler; SURVEY 8(f)-1 "cache the

@@ -41,6 +41,27 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(
   for (int i = lane; i < D / 4; i += 64) o[i] = s[i];
 }
 
+// dst rows i < *n_rows_dev are copies of src rows gather[i]: the fp32 residual
+// stream and the bf16 attention output of the rows the last block still has to
+// finish (the masked positions), packed densely.
+__global__ __launch_bounds__(256) void gather_rows_kernel(
+    const float* __restrict__ xs, float* __restrict__ xd,
+    const bf16_t* __restrict__ as, bf16_t* __restrict__ ad,
+    const int32_t* __restrict__ gather, int D, int64_t n_rows,
+    const int32_t* __restrict__ n_rows_dev) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t live = n_rows_dev ? (int64_t)*n_rows_dev : n_rows;
+  if (r >= n_rows || r >= live) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t sr = gather[r];
+  const float4* s4 = reinterpret_cast<const float4*>(xs + sr * D);
+  float4* d4 = reinterpret_cast<float4*>(xd + r * D);
+  for (int i = lane; i < D / 4; i += 64) d4[i] = s4[i];
+  const uint4* s8 = reinterpret_cast<const uint4*>(as + sr * D);
+  uint4* d8 = reinterpret_cast<uint4*>(ad + r * D);
+  for (int i = lane; i < D / 8; i += 64) d8[i] = s8[i];
+}
+
 __global__ void timestep_embedding_kernel(const float* __restrict__ t,
                                           float* __restrict__ out, int B, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -199,6 +220,21 @@ extern "C" int mdlm_scatter_rows_f32(const float* src, float* dst,
   MDLM_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "scatter_rows_f32: 16-byte alignment");
   if (n_rows == 0) return 0;
   scatter_rows_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, ST(stream)>>>(src, dst, sample_map, L, D, n_rows, n_rows_dev);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mdlm_gather_rows(const float* x_src, float* x_dst, const void* a_src,
+                                void* a_dst, const int32_t* gather, int D,
+                                int64_t n_rows, const int32_t* n_rows_dev,
+                                void* stream) {
+  if (n_rows == 0) return 0;
+  MDLM_CHECK_ARG(x_src && x_dst && a_src && a_dst && gather, "gather_rows: null pointer");
+  MDLM_CHECK_ARG(D > 0 && D % 8 == 0 && n_rows > 0, "gather_rows: D must be a multiple of 8");
+  MDLM_CHECK_ARG((((uintptr_t)x_src | (uintptr_t)x_dst | (uintptr_t)a_src | (uintptr_t)a_dst) & 15) == 0,
+                 "gather_rows: 16-byte alignment");
+  gather_rows_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, ST(stream)>>>(
+    x_src, x_dst, (const bf16_t*)a_src, (bf16_t*)a_dst, gather, D, n_rows, n_rows_dev);
   MDLM_LAUNCH_CHECK();
   return 0;
 }

@@ -184,7 +184,10 @@ class DIT(nn.Module):
       h=torch.empty(M, D, dtype=bf, device=dev),
       qkv=torch.empty(3 * M * D, dtype=bf, device=dev),
       ao=torch.empty(M, D, dtype=bf, device=dev),
-      mh=torch.empty(M, 4 * D, dtype=bf, device=dev))
+      mh=torch.empty(M, 4 * D, dtype=bf, device=dev),
+      # dense copies of the masked rows for the tail of the last block
+      xm=torch.empty(M, D, dtype=torch.float32, device=dev),
+      aom=torch.empty(M, D, dtype=bf, device=dev))
     return self._ws
 
   # ------------------------------------------------------------ conditioning
@@ -261,7 +264,13 @@ class DIT(nn.Module):
     rows_t = None
     if ev is not None:  # one host copy of the live row count per forward
       rows_t = n_rows_dev.clone() if n_rows_dev is not None else M
-    for bp, mod in zip(p['blocks'], mods):
+    # With a row map (only the masked rows' logits are read) the last block
+    # stops being full-width after its attention: out-projection, MLP and the
+    # final layer are row-wise, so they run on the gathered masked rows only.
+    tail_rows = (row_map is not None and n_mod == 1 and hidden_out is None
+                 and getattr(self, 'tail_rows', True))
+    n_blocks = len(p['blocks'])
+    for bi, (bp, mod) in enumerate(zip(p['blocks'], mods)):
       # chunk order dit.py:249-250: shift_msa, scale_msa, gate_msa, shift_mlp,
       # scale_mlp, gate_mlp
       ops.ln_modulate(x, bp['n1'], mod[:, 0:D], mod[:, D:2 * D], h, L, n_mod,
@@ -270,6 +279,30 @@ class DIT(nn.Module):
                     rot_cos=p['cos'], rot_sin=p['sin'], n_heads=H,
                     m_rows_dev=n_rows_dev, ldc=0, M=M)
       ops.attn_fwd(q_, k_, vt_, ao, n_seq, H, L, n_seq_dev=n_active_dev)
+      if tail_rows and bi == n_blocks - 1:
+        gather, scatter, live = row_map
+        xm, aom = ws['xm'][:M], ws['aom'][:M]
+        ops.gather_rows(x, xm, ao, aom, gather, n_rows_dev=live, rows=M)
+        lt = live.clone() if ev is not None else None
+        self._timed('gate_residual', lt, 2.0 * D * D, lambda: ops.gemm_bf16(
+          aom, bp['out'], xm, EPI_GATE_RESIDUAL, gate=mod[:, 2 * D:3 * D],
+          residual=xm, rows_per_mod=L, n_mod=1, mod_ld=ld6, m_rows_dev=live, M=M))
+        ops.ln_modulate(xm, bp['n2'], mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D], h,
+                        L, 1, ld6, live)
+        ops.gemm_bf16(h, bp['fc1'], mh, EPI_BIAS_GELU, bias=bp['b1'],
+                      m_rows_dev=live, M=M)
+        self._timed('gate_residual', lt, 2.0 * D * 4 * D, lambda: ops.gemm_bf16(
+          mh, bp['fc2'], xm, EPI_GATE_RESIDUAL, bias=bp['b2'],
+          gate=mod[:, 5 * D:6 * D], residual=xm, rows_per_mod=L, n_mod=1,
+          mod_ld=ld6, m_rows_dev=live, M=M))
+        fm = mods[-1]
+        V = self.vocab_size
+        ops.ln_modulate(xm, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, 1,
+                        ld2, live)
+        self._timed('vocab', lt, 2.0 * V * D, lambda: ops.gemm_bf16(
+          h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
+          m_rows_dev=live, out_row_map=scatter, ldc=logits_out.stride(-2), M=M))
+        return logits_out
       self._timed('gate_residual', rows_t, 2.0 * D * D, lambda: ops.gemm_bf16(
         ao, bp['out'], x, EPI_GATE_RESIDUAL, gate=mod[:, 2 * D:3 * D],
         residual=x, rows_per_mod=L, n_mod=n_mod, mod_ld=ld6,

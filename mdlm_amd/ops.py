@@ -223,6 +223,16 @@ def scatter_rows_f32(src, dst, sample_map, L, n_rows_dev=None):
   return dst
 
 
+def gather_rows(x_src, x_dst, a_src, a_dst, gather, n_rows_dev=None, rows=None):
+  """Dense copies of the listed rows of the fp32 residual stream and of the
+  bf16 attention output (see include/mdlm_hip.h)."""
+  D = x_src.shape[1]
+  if rows is None:
+    rows = x_dst.shape[0]
+  call('mdlm_gather_rows', x_src.data_ptr(), x_dst.data_ptr(), a_src.data_ptr(),
+       a_dst.data_ptr(), gather.data_ptr(), D, int(rows), _p(n_rows_dev), _stream())
+
+
 def philox_uniform(rows, V, seed, offset=0, device='cuda'):
   out = torch.empty(rows, V, dtype=torch.float32, device=device)
   call('mdlm_philox_uniform', out.data_ptr(), rows, V, int(seed), int(offset),
