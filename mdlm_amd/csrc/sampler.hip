@@ -216,6 +216,94 @@ __global__ __launch_bounds__(NT) void subs_logprobs_vec_kernel(
   }
 }
 
+// bf16 rows of up to REG_VEC * NT * 8 elements (51,200: the GPT-2 vocabulary fits):
+// the row is read from HBM ONCE into registers (25 x 16 bytes per thread, all
+// loads in flight together), the log-sum-exp is taken over the registers in the
+// same per-thread order as subs_row_lse, and the normalised row is written from
+// them -- one read + one write per masked row instead of two reads + one write.
+constexpr int REG_VEC = 25;
+template <bool PROBS>
+__global__ __launch_bounds__(NT, 3) void subs_logprobs_reg_kernel(
+    const bf16_t* __restrict__ logits, int64_t ld_in, const int64_t* __restrict__ xt,
+    bf16_t* __restrict__ out, int64_t ld_out, int V, int mask) {
+  __shared__ float sm[9];
+  const int64_t r = blockIdx.x;
+  const bf16_t* row = logits + r * ld_in;
+  bf16_t* orow = out + r * ld_out;
+  const int64_t tok = xt[r];
+  const int nvec = V / 8;
+  uint4* ov = reinterpret_cast<uint4*>(orow);
+  if (tok != mask) {  // diffusion.py:274-276
+    const unsigned fill = PROBS ? 0u : pack_bf16x2(NEG_INF, NEG_INF);
+    for (int i = threadIdx.x; i < nvec; i += NT) {
+      uint4 o = make_uint4(fill, fill, fill, fill);
+      if ((unsigned)(tok - (int64_t)i * 8) < 8u) {
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          f[k] = (i * 8 + k == tok) ? (PROBS ? 1.f : 0.f) : (PROBS ? 0.f : NEG_INF);
+        o = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
+                       pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+      }
+      ov[i] = o;
+    }
+    for (int i = nvec * 8 + threadIdx.x; i < V; i += NT)
+      elem<bf16_t>::store(orow + i, i == tok ? (PROBS ? 1.f : 0.f) : (PROBS ? 0.f : NEG_INF));
+    return;
+  }
+  const uint4* iv = reinterpret_cast<const uint4*>(row);
+  uint4 reg[REG_VEC];
+#pragma unroll
+  for (int j = 0; j < REG_VEC; ++j) {
+    const int i = threadIdx.x + j * NT;
+    reg[j] = i < nvec ? iv[i] : make_uint4(0u, 0u, 0u, 0u);
+  }
+  LseState st;
+#pragma unroll
+  for (int j = 0; j < REG_VEC; ++j) {
+    const int i = threadIdx.x + j * NT;
+    if (i < nvec) {
+      float f[8];
+      unpack<bf16_t>(reg[j], f);
+      if ((unsigned)(mask - i * 8) < 8u) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (i * 8 + k == mask) f[k] += NEG_INF;
+      }
+      st.addv(f);
+    }
+  }
+  for (int i = nvec * 8 + threadIdx.x; i < V; i += NT) {
+    const float x = elem<bf16_t>::load(row + i);
+    st.add1(i == mask ? x + NEG_INF : x);
+  }
+  const float lse = block_lse(st, sm);
+  // keep the row PACKED across the reduction: without this the compiler reuses
+  // the first pass's unpacked fp32 values (200 more registers, one wave per SIMD)
+#pragma unroll
+  for (int j = 0; j < REG_VEC; ++j)
+    asm volatile("" : "+v"(reg[j].x), "+v"(reg[j].y), "+v"(reg[j].z), "+v"(reg[j].w));
+#pragma unroll
+  for (int j = 0; j < REG_VEC; ++j) {
+    const int i = threadIdx.x + j * NT;
+    if (i < nvec) {
+      float f[8];
+      unpack<bf16_t>(reg[j], f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (i * 8 + k == mask) f[k] += NEG_INF;
+        f[k] = PROBS ? expf(f[k] - lse) : f[k] - lse;
+      }
+      ov[i] = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
+                         pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+    }
+  }
+  for (int i = nvec * 8 + threadIdx.x; i < V; i += NT) {
+    float x = elem<bf16_t>::load(row + i);
+    if (i == mask) x += NEG_INF;
+    elem<bf16_t>::store(orow + i, PROBS ? expf(x - lse) : x - lse);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void subs_row_lse_kernel(
     const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ xt,
@@ -828,7 +916,8 @@ extern "C" int mdlm_subs_logprobs(const void* logits, int64_t ld_in, int dtype_i
     if (vec) subs_logprobs_vec_kernel<float, P><<<g, b, 0, ST(stream)>>>((const float*)logits, ld_in, xt, (float*)out, ld_out, V, mask_index); \
     else subs_logprobs_kernel<float, float, P><<<g, b, 0, ST(stream)>>>((const float*)logits, ld_in, xt, (float*)out, ld_out, V, mask_index); \
   } else if (dtype_in == MDLM_BF16 && dtype_out == MDLM_BF16) { \
-    if (vec) subs_logprobs_vec_kernel<bf16_t, P><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index); \
+    if (vec && V / 8 <= REG_VEC * NT) subs_logprobs_reg_kernel<P><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index); \
+    else if (vec) subs_logprobs_vec_kernel<bf16_t, P><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index); \
     else subs_logprobs_kernel<bf16_t, bf16_t, P><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (bf16_t*)out, ld_out, V, mask_index); \
   } else if (dtype_in == MDLM_BF16) { \
     subs_logprobs_kernel<bf16_t, float, P><<<g, b, 0, ST(stream)>>>((const bf16_t*)logits, ld_in, xt, (float*)out, ld_out, V, mask_index); \
