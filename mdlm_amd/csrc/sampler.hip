@@ -108,10 +108,13 @@ struct ArgMax {
   float v = -INFINITY; int i = 0x7fffffff;
   // torch.argmax semantics: NaN counts as the maximum and the first index
   // wins ties; per thread the visit order is ascending, so strict > suffices.
+  // Branch-free (two compares, lane-mask logic, two selects) so that the row
+  // loop can be unrolled with several vector loads in flight.
   __device__ __forceinline__ void put(float x, int idx) {
-    if (i == 0x7fffffff) { v = x; i = idx; return; }
-    if (v != v) return;
-    if (x > v || x != x) { v = x; i = idx; }
+    const bool first = i == 0x7fffffff;
+    const bool take = first | ((v == v) & ((x != x) | (x > v)));
+    v = take ? x : v;
+    i = take ? idx : i;
   }
 };
 __device__ __forceinline__ bool am_better(float av, int ai, float bv, int bi) {
