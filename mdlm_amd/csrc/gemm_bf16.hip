@@ -45,7 +45,7 @@ struct GemmArgs {
   const int32_t* out_row_map;
   const float* rot_cos; const float* rot_sin; int n_heads;
   const int32_t* m_rows_dev;
-  int tiles_m, tiles_n, seq_len;
+  int tiles_m, tiles_n;
   int vec_ok;  // ldc / alignment allow 16-byte row stores
   int dbg;     // timing experiments only (2: skip the epilogue, 4: drop the stores)
 };
@@ -347,28 +347,39 @@ void gemm_bf16_kernel(GemmArgs g) {
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid / WN, wc = wid - wr * WN;
-  // ---- XCD-aware, persistent tile walk -----------------------------------
-  // Workgroup b belongs to XCD group b & 7 and walks that group's tile
-  // sequence (groups of 1024 A rows x all N tiles, N outer) with stride
-  // gridDim/8: the workgroups resident on one XCD work on neighbouring tiles
-  // (shared A panels in its L2).  The K slabs of consecutive tiles form ONE
-  // double-buffered stream: the last K step of tile i prefetches the first
-  // slab of tile i+1, whose load latency and the stores of tile i then overlap.
+  // ---- XCD-aware, persistent, balanced tile walk --------------------------
+  // The valid tiles (M tiles below the live row count x all N tiles) form one
+  // sequence: groups of 1024 A rows x all N tiles, N outer inside a group, so
+  // neighbours share A panels.  It is cut into 8 equal contiguous ranges, one
+  // per XCD (workgroup b runs on XCD b & 7: its range stays in that XCD's
+  // L2), and the gridDim/8 workgroups of an XCD stride through their range.
+  // The cut is made on the live tile count, so the XCDs finish within one tile
+  // of each other whatever the row count (a per-sample partition left up to
+  // 7/8 of a sample's tiles of imbalance).  The K slabs of consecutive tiles
+  // form ONE double-buffered stream: the last K step of tile i prefetches the
+  // first slab of tile i+1, whose load latency and the stores of tile i overlap.
   const int bid = blockIdx.x;
   const int xcd = bid & 7;
   const int slots = gridDim.x >> 3;
   const int per_group = GROUP_M * g.tiles_n;
   const int64_t m_lim = g.m_rows_dev ? (int64_t)*g.m_rows_dev : g.M;
-  // next valid tile at or after sequence index j (-1: none)
+  const int64_t vm_live = (m_lim + TBM - 1) / TBM;
+  const int vm = vm_live < g.tiles_m ? (int)vm_live : g.tiles_m;  // valid M tiles
+  const int total = vm * g.tiles_n;
+  const int per_xcd = (total + 7) >> 3;
+  const int s_begin = xcd * per_xcd;
+  const int s_end = total < s_begin + per_xcd ? total : s_begin + per_xcd;
+  // tile at index j of this XCD's range (-1: past its end)
   auto next_tile = [&](int j, int& tm, int& tn) -> int {
-    for (; j < g.seq_len; j += slots) {
-      const int gl = j / per_group;
-      const int rem = j - gl * per_group;
-      tn = rem / GROUP_M;
-      tm = (gl * 8 + xcd) * GROUP_M + (rem - tn * GROUP_M);
-      if (tm < g.tiles_m && (int64_t)tm * TBM < m_lim) return j;
-    }
-    return -1;
+    const int s = s_begin + j;
+    if (s >= s_end) return -1;
+    const int gl = s / per_group;
+    const int rem = s - gl * per_group;
+    const int left = vm - gl * GROUP_M;
+    const int gm = left < GROUP_M ? left : GROUP_M;  // the last group may be partial
+    tn = rem / gm;
+    tm = gl * GROUP_M + (rem - tn * gm);
+    return j;
   };
 
   // ---- staging addresses -------------------------------------------------
@@ -562,7 +573,6 @@ template <int EPI, typename TC, int WM, int WN, int MT>
 static int launch_cfg(GemmArgs g, hipStream_t s) {
   constexpr int TBM = WM * MT * 16, TBN = WN * 64;
   constexpr int LDS = 2 * (TBM + TBN) * BK * 2;
-  constexpr int GROUP_M = 1024 / TBM;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(
@@ -573,10 +583,7 @@ static int launch_cfg(GemmArgs g, hipStream_t s) {
   }
   g.tiles_m = (int)(g.M / TBM);
   g.tiles_n = (g.N + TBN - 1) / TBN;
-  const int groups = (g.tiles_m + GROUP_M - 1) / GROUP_M;
-  const int gl = (groups + 7) / 8;
-  g.seq_len = gl * GROUP_M * g.tiles_n;
-  int64_t grid = (int64_t)8 * g.seq_len;
+  int64_t grid = (((int64_t)g.tiles_m * g.tiles_n + 7) / 8) * 8;
   if (grid >= (1ll << 31)) { set_error("gemm: grid too large"); return -1; }
   // persistent launch: one workgroup per CU for the 128 KiB-LDS tile, two for
   // the 64 KiB one
