@@ -436,6 +436,68 @@ def main():
   np.savez(os.path.join(OUT, 'g10_d3pm_loss.npz'), x0=x0.numpy(), attn=attn.numpy(),
            u_t=u_t.numpy(), u_xt=u_xt.numpy(), T=np.int64(8),
            nlls=loss.nlls.numpy(), token_nll=loss.loss.numpy())
+  # ---------------- G11: training steps (tiny model, dropout 0) -----------
+  # training_step (diffusion.py:390-397) -> _loss in train mode, backward,
+  # clip_grad_norm_ 1.0 (configs/config.yaml:69), AdamW (449-459), the
+  # constant-with-warmup schedule stepped per optimizer step, and the
+  # reference's own EMA class (models/ema.py) -- three optimizer steps.
+  import models.ema as ref_ema
+  import transformers
+  cfg0 = types.SimpleNamespace(model=types.SimpleNamespace(
+    hidden_size=tc.hidden, cond_dim=tc.cond_dim, n_heads=tc.n_heads,
+    n_blocks=tc.n_blocks, dropout=0.0, scale_by_sigma=True))
+  ref_t = ref_dit.DIT(cfg0, vocab_size=V)
+  ref_t.load_state_dict(load)
+  ref_t.train()
+  ns = make_self(diffusion, noise_schedule, ref_t, mask, V, tc.length, 4)
+  names = [k for k, _ in ref_t.named_parameters()]
+  plist = [q for _, q in ref_t.named_parameters()]
+  opt = torch.optim.AdamW(plist, lr=3e-3, betas=(0.9, 0.999), eps=1e-8,
+                          weight_decay=0)
+  sched = transformers.get_constant_schedule_with_warmup(opt, num_warmup_steps=2)
+  ema = ref_ema.ExponentialMovingAverage(plist, decay=0.9999)
+  keep_keys = ['vocab_embed.embedding', 'sigma_map.mlp.0.weight',
+               'blocks.0.norm1.weight', 'blocks.0.attn_qkv.weight',
+               'blocks.0.adaLN_modulation.weight', 'blocks.1.attn_out.weight',
+               'blocks.1.mlp.0.bias', 'blocks.1.mlp.2.weight',
+               'blocks.1.adaLN_modulation.bias',
+               'output_layer.norm_final.weight', 'output_layer.linear.weight',
+               'output_layer.linear.bias', 'output_layer.adaLN_modulation.weight']
+  g11 = {'names': np.array(names), 'keep_keys': np.array(keep_keys)}
+  torch.manual_seed(111)
+  with torch.enable_grad():
+    for it in range(3):
+      x0 = torch.randint(0, V - 1, (4, tc.length))
+      attn = torch.ones(4, tc.length)
+      attn[1, -2:] = 0
+      st = torch.get_rng_state()
+      u_t = torch.rand(4); u_xt = torch.rand(4, tc.length)
+      torch.set_rng_state(st)
+      opt.zero_grad()
+      loss = D._loss(ns, x0, attn).loss
+      loss.backward()
+      gn = torch.nn.utils.clip_grad_norm_(plist, 1.0)
+      g11[f'lr{it}'] = np.float64(opt.param_groups[0]['lr'])
+      g11[f'x0_{it}'] = x0.numpy(); g11[f'attn{it}'] = attn.numpy()
+      g11[f'u_t{it}'] = u_t.numpy(); g11[f'u_xt{it}'] = u_xt.numpy()
+      g11[f'loss{it}'] = loss.detach().numpy()
+      g11[f'grad_norm{it}'] = gn.detach().numpy()
+      # gradients after clipping (what AdamW consumes)
+      g11[f'gnorms{it}'] = np.array([q.grad.norm().item() for q in plist])
+      if it == 0:
+        for k in keep_keys:
+          g11['grad0/' + k] = dict(zip(names, plist))[k].grad.detach().numpy()
+      opt.step()
+      sched.step()
+      ema.update(plist)
+      g11[f'pnorms{it}'] = np.array([q.detach().double().norm().item() for q in plist])
+      g11[f'enorms{it}'] = np.array([q.double().norm().item() for q in ema.shadow_params])
+  for k in keep_keys:
+    i = names.index(k)
+    g11['param3/' + k] = plist[i].detach().numpy()
+    g11['ema3/' + k] = ema.shadow_params[i].numpy()
+  np.savez(os.path.join(OUT, 'g11_train_steps.npz'), **g11)
+  torch.set_grad_enabled(False)
   tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
   print('golden written to', OUT, 'bytes', tot)
 

@@ -257,8 +257,19 @@ def modulate(x, shift, scale):
   return x * (1 + scale) + shift
 
 
-def dit_block(p, pre, x, cos, sin, c, n_heads):
-  """dit.py:244-288 (eval mode: dropout is the identity)."""
+def _dropout(y, keep, prob):
+  """F.dropout(y, p=prob, training=True) (dit.py:27-29) with the keep mask
+  supplied by the caller; keep=None is eval mode (identity)."""
+  if keep is None:
+    return y
+  return y * keep.to(y.dtype) / (1.0 - prob)
+
+
+def dit_block(p, pre, x, cos, sin, c, n_heads, keep=None, prob=0.1):
+  """dit.py:244-288.  `keep` = None (eval: dropout is the identity) or a pair
+  of (B,L,D) keep masks for the two bias_dropout_add_scale calls (training,
+  dit.py:20-34, 277-287)."""
+  k1, k2 = keep if keep is not None else (None, None)
   B, L, D = x.shape
   mod = F.linear(c, p[pre + 'adaLN_modulation.weight'],
                  p[pre + 'adaLN_modulation.bias'])[:, None]
@@ -272,16 +283,17 @@ def dit_block(p, pre, x, cos, sin, c, n_heads):
   q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))  # (B,H,L,d)
   a = F.scaled_dot_product_attention(q, k, v)  # dit.py:272-273 (non-causal)
   a = a.transpose(1, 2).reshape(B, L, D)
-  x = x_skip + gate_msa * F.linear(a, p[pre + 'attn_out.weight'])
+  x = x_skip + gate_msa * _dropout(F.linear(a, p[pre + 'attn_out.weight']), k1, prob)
   h = modulate(layer_norm_w(x, p[pre + 'norm2.weight']), shift_mlp, scale_mlp)
   h = F.linear(h, p[pre + 'mlp.0.weight'], p[pre + 'mlp.0.bias'])
   h = F.gelu(h, approximate='tanh')
   h = F.linear(h, p[pre + 'mlp.2.weight'], p[pre + 'mlp.2.bias'])
-  return x + gate_mlp * h
+  return x + gate_mlp * _dropout(h, k2, prob)
 
 
-def dit_forward(p, indices, sigma, n_heads, n_blocks):
-  """dit.py:359-370 with a flat state-dict `p` (reference key names)."""
+def dit_forward(p, indices, sigma, n_heads, n_blocks, keep=None, prob=0.1):
+  """dit.py:359-370 with a flat state-dict `p` (reference key names).  `keep`:
+  None (eval) or a list of per-block keep-mask pairs (training)."""
   x = p['vocab_embed.embedding'][indices]
   cond_dim = p['sigma_map.mlp.0.weight'].shape[0]
   freq = p['sigma_map.mlp.0.weight'].shape[1]
@@ -295,7 +307,8 @@ def dit_forward(p, indices, sigma, n_heads, n_blocks):
   D = x.shape[-1]
   cos, sin = rotary_cos_sin(x.shape[1], D // n_heads)
   for i in range(n_blocks):
-    x = dit_block(p, f'blocks.{i}.', x, cos, sin, c, n_heads)
+    x = dit_block(p, f'blocks.{i}.', x, cos, sin, c, n_heads,
+                  None if keep is None else keep[i], prob)
   mod = F.linear(c, p['output_layer.adaLN_modulation.weight'],
                  p['output_layer.adaLN_modulation.bias'])[:, None]
   shift, scale = mod.chunk(2, dim=2)
@@ -492,6 +505,103 @@ def nelbo_from_logits(logits, xt, x0, t, attention_mask, mask_index):
 def perplexity(nll_sum, weight_sum):
   """diffusion.py:58-65 (fp64 MeanMetric): exp(sum(nll*w)/sum(w))."""
   return math.exp(float(nll_sum) / float(weight_sum))
+
+
+# --------------------------------------------------------------------------
+# Training step (SURVEY §8 f-3): loss + autograd gradients, global-norm clip,
+# AdamW, EMA, constant-with-warmup learning rate
+# --------------------------------------------------------------------------
+def training_loss(params, x0, attention_mask, t, u_xt, n_heads, n_blocks,
+                  mask_index, keep=None, prob=0.1):
+  """diffusion.py:390-397 -> _compute_loss (360-384) -> _loss (896-916) with
+  the backbone in train mode.  Returns (token_nll, nlls)."""
+  sigma, dsigma = loglinear_noise(t)
+  move_chance = 1 - torch.exp(-sigma[:, None])
+  xt = q_xt(x0, move_chance, u_xt, mask_index)
+  logits = dit_forward(params, xt, torch.zeros_like(sigma), n_heads, n_blocks,
+                       keep, prob)
+  lp = subs_parameterization(logits, xt, mask_index)
+  log_p_theta = torch.gather(lp, -1, x0[:, :, None]).squeeze(-1)
+  loss = -log_p_theta * (dsigma / torch.expm1(sigma))[:, None]
+  nlls = loss * attention_mask
+  return nlls.sum() / attention_mask.sum(), nlls
+
+
+def loss_and_grads(params, *args, **kwargs):
+  """Gradients of `training_loss` w.r.t. every entry of the flat state dict
+  (torch autograd on the fp32 CPU restatement)."""
+  leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+  with torch.enable_grad():
+    loss, nlls = training_loss(leaves, *args, **kwargs)
+    grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+  return loss.detach(), nlls.detach(), {
+    k: (g if g is not None else torch.zeros_like(params[k]))
+    for k, g in zip(leaves, grads)}
+
+
+def clip_coef(grads, max_norm=1.0):
+  """Lightning `gradient_clip_val: 1.0` (configs/config.yaml:69) ->
+  torch.nn.utils.clip_grad_norm_: total 2-norm over all gradients,
+  coef = min(1, max_norm / (total + 1e-6)).  Returns (total_norm, coef)."""
+  total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+  return total, torch.clamp(max_norm / (total + 1e-6), max=1.0)
+
+
+def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8,
+               weight_decay=0.0):
+  """torch.optim.AdamW as configured at diffusion.py:449-459 (single-tensor
+  path of torch/optim/adamw.py): decoupled decay, bias-corrected moments.
+  `step` is 1-based.  Updates p, m, v in place."""
+  p.mul_(1 - lr * weight_decay)
+  m.lerp_(g, 1 - beta1)
+  v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+  bc1 = 1 - beta1 ** step
+  bc2 = 1 - beta2 ** step
+  denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+  p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def ema_decay(decay, num_updates):
+  """models/ema.py:40-43 (`num_updates` already incremented)."""
+  return min(decay, (1 + num_updates) / (10 + num_updates))
+
+
+def ema_update(shadow, p, decay, num_updates):
+  """models/ema.py:29-49: s -= (1 - decay_t) * (s - p)."""
+  shadow.sub_((1.0 - ema_decay(decay, num_updates)) * (shadow - p))
+
+
+def constant_warmup_lr(base_lr, step, num_warmup_steps=2500):
+  """configs/lr_scheduler/constant_warmup.yaml ->
+  transformers.get_constant_schedule_with_warmup: the lr used by optimizer step
+  number `step` (0-based) is base_lr * min(1, step / max(1, warmup))."""
+  if step < num_warmup_steps:
+    return base_lr * float(step) / float(max(1.0, num_warmup_steps))
+  return base_lr
+
+
+def training_step(state, x0, attention_mask, t, u_xt, n_heads, n_blocks,
+                  mask_index, lr, keep=None, prob=0.1, max_norm=1.0,
+                  ema=0.9999, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+  """One optimizer step on `state` = dict(params, m, v, shadow, step):
+  loss.backward -> clip -> AdamW (diffusion.py:449-459) -> EMA update
+  (diffusion.py:254-259).  Returns (loss, total_norm, grads)."""
+  loss, _, grads = loss_and_grads(state['params'], x0, attention_mask, t, u_xt,
+                                  n_heads, n_blocks, mask_index, keep, prob)
+  total, coef = clip_coef(grads, max_norm)
+  state['step'] += 1
+  for k, p in state['params'].items():
+    adamw_step(p, grads[k] * coef, state['m'][k], state['v'][k], state['step'],
+               lr, betas[0], betas[1], eps, weight_decay)
+    ema_update(state['shadow'][k], p, ema, state['step'])
+  return loss, total, grads
+
+
+def new_train_state(params):
+  return dict(params={k: v.clone() for k, v in params.items()},
+              m={k: torch.zeros_like(v) for k, v in params.items()},
+              v={k: torch.zeros_like(v) for k, v in params.items()},
+              shadow={k: v.clone() for k, v in params.items()}, step=0)
 
 
 def tiny_config():

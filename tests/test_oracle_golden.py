@@ -218,3 +218,38 @@ def test_g10_d3pm_loss():
                              equal_nan=True)
   torch.testing.assert_close(token_nll, _t(g['token_nll']), rtol=1e-5,
                              atol=1e-6, equal_nan=True)
+
+
+def test_g11_training_steps():
+  """Three optimizer steps of the reference (training_step -> backward ->
+  clip_grad_norm_ 1.0 -> AdamW -> warmup schedule -> models/ema.py) against the
+  oracle's restatement."""
+  g = _g('g11_train_steps.npz')
+  tc, p = _tiny()
+  names = [str(n) for n in g['names']]
+  assert set(names) == set(p)
+  keep = [str(k) for k in g['keep_keys']]
+  st = orc.new_train_state(p)
+  for it in range(3):
+    lr = orc.constant_warmup_lr(3e-3, it, num_warmup_steps=2)
+    assert abs(lr - float(g[f'lr{it}'])) < 1e-12
+    t = orc.sample_t(4, _t(g[f'u_t{it}']))
+    loss, total, grads = orc.training_step(
+      st, _t(g[f'x0_{it}']), _t(g[f'attn{it}']), t, _t(g[f'u_xt{it}']),
+      tc.n_heads, tc.n_blocks, tc.vocab - 1, lr=lr)
+    torch.testing.assert_close(loss, _t(g[f'loss{it}']), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(total, _t(g[f'grad_norm{it}']), rtol=1e-4, atol=1e-6)
+    _, coef = orc.clip_coef(grads)
+    gn = torch.tensor([float((grads[n] * coef).norm()) for n in names])
+    torch.testing.assert_close(gn, _t(g[f'gnorms{it}']).float(), rtol=2e-4, atol=1e-7)
+    if it == 0:
+      for k in keep:
+        torch.testing.assert_close(grads[k] * coef, _t(g['grad0/' + k]),
+                                   rtol=1e-4, atol=1e-7)
+    pn = torch.tensor([float(st['params'][n].double().norm()) for n in names])
+    en = torch.tensor([float(st['shadow'][n].double().norm()) for n in names])
+    torch.testing.assert_close(pn, _t(g[f'pnorms{it}']).float(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(en, _t(g[f'enorms{it}']).float(), rtol=1e-5, atol=1e-7)
+  for k in keep:
+    torch.testing.assert_close(st['params'][k], _t(g['param3/' + k]), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(st['shadow'][k], _t(g['ema3/' + k]), rtol=1e-5, atol=1e-6)
