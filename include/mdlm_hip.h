@@ -301,6 +301,104 @@ int mdlm_masked_row_map(const int64_t* x, const int32_t* active,
                         int32_t* gather, int32_t* scatter, int32_t* n_out,
                         void* stream);
 
+/* ------------------------------------------------------------ training step
+ * SURVEY §8 (f)-3.  The reference obtains every backward from torch autograd
+ * (and flash-attn's backward); these are the hand-written halves for the DiT
+ * block under bf16 autocast with an fp32 residual stream.  Backward GEMMs are
+ * mdlm_gemm_bf16 on operands made K-contiguous by mdlm_transpose_bf16. */
+
+/* mdlm_attn_fwd that also writes lse (n_seq,H,L) fp32 = log2-domain
+ * log-sum-exp of the scaled scores, the statistic flash-attn saves for its
+ * backward (dit.py:272-273 under autograd). */
+int mdlm_attn_fwd_lse(const void* q, const void* k, const void* vt, void* out,
+                      float* lse, int n_seq, int H, int L, void* stream);
+
+/* Backward of dit.py:265-275: q,k head-major, vt, o/dout (n_seq*L, H*64),
+ * lse from mdlm_attn_fwd_lse, delta_ws (n_seq*H*L fp32 workspace) ->
+ * dq, dk, dv head-major (n_seq,H,L,64) bf16.  L % 64 == 0.  No atomics. */
+int mdlm_attn_bwd(const void* q, const void* k, const void* vt, const void* o,
+                  const void* dout, const float* lse, float* delta_ws, void* dq,
+                  void* dk, void* dv, int n_seq, int H, int L, void* stream);
+
+/* d(qkv) (n_seq*L, 3*H*64) bf16 from dq, dk, dv: inverse rotary on dq / dk
+ * (dit.py:112-115 transposed) + the 'three h d' packing of dit.py:257-260. */
+int mdlm_qkv_grad_pack(const void* dq, const void* dk, const void* dv,
+                       const float* rot_cos, const float* rot_sin, void* dqkv,
+                       int n_seq, int H, int L, void* stream);
+
+/* Backward of mdlm_ln_modulate (dit.py:126-134 + 74-78): dx_inout (+)= dLN,
+ * partial[(rows+31)/32][3][D] = per-32-row column sums of (dw, dscale, dshift). */
+int mdlm_ln_modulate_bwd(const void* dh_bf16, const float* x, const float* ln_w,
+                         const float* scale, float* dx_inout, float* partial,
+                         int64_t rows, int D, int64_t rows_per_mod, int n_mod,
+                         int64_t mod_ld, int accumulate, void* stream);
+
+/* out[o][c] = sum_{i < per_out} partial[o*per_out + i][c] (fixed order). */
+int mdlm_colsum_reduce(const float* partial, float* out, int64_t C, int per_out,
+                       int n_out, void* stream);
+
+/* partial[(rows+127)/128][N] = per-128-row column sums of a bf16 matrix (bias
+ * gradients: the reference's autograd of nn.Linear bias, dit.py:224-227, 306). */
+int mdlm_colsum_bf16_partial(const void* x_bf16, int64_t ld, float* partial,
+                             int64_t rows, int N, void* stream);
+
+/* bias_dropout_add_scale with training=True (dit.py:20-34): out = residual +
+ * gate * dropout(y, p); keep mask = Philox(seed, offset) in the element layout
+ * of mdlm_philox_uniform(rows, D), regenerated by the backward. */
+int mdlm_dropout_gate_residual_fwd(const void* y_bf16, const float* gate,
+                                   const float* residual, float* out,
+                                   int64_t rows, int D, int64_t rows_per_mod,
+                                   int n_mod, int64_t mod_ld, float p,
+                                   uint64_t seed, uint64_t offset, void* stream);
+
+/* dy = dout * gate * keep/(1-p) (bf16); partial[(rows+31)/32][D] = per-32-row
+ * column sums of dout * dropout(y) (the gate gradient). */
+int mdlm_dropout_gate_residual_bwd(const float* dout, const void* y_bf16,
+                                   const float* gate, void* dy_bf16,
+                                   float* partial, int64_t rows, int D,
+                                   int64_t rows_per_mod, int n_mod,
+                                   int64_t mod_ld, float p, uint64_t seed,
+                                   uint64_t offset, void* stream);
+
+/* GELU(tanh) of dit.py:226 and its derivative, bf16 elementwise (n % 8 == 0). */
+int mdlm_gelu_fwd(const void* pre_bf16, void* act_bf16, int64_t n, void* stream);
+int mdlm_gelu_bwd(const void* dact_bf16, const void* pre_bf16, void* dpre_bf16,
+                  int64_t n, void* stream);
+
+/* out[b][c][r] = in[b][r][c], bf16 (operand layout for the backward GEMMs;
+ * no reference counterpart: torch.matmul takes strided operands). */
+int mdlm_transpose_bf16(const void* in, int64_t ld_in, int64_t batch_stride_in,
+                        void* out, int64_t ld_out, int64_t batch_stride_out,
+                        int R, int C, int batch, void* stream);
+
+/* dtable[idx[r]] += dx[r] (fp32 atomics): backward of dit.py:298-299. */
+int mdlm_embed_grad(const float* dx, const int64_t* idx, float* dtable,
+                    int64_t rows, int D, int vocab, void* stream);
+
+/* d(loss)/d(logits) of diffusion.py:261-277 + 884-916 for loss = sum_r
+ * row_weight[r] * nll[r]: w*(softmax - onehot(x0)) on masked rows, 0 in the
+ * mask column, on unmasked rows and in the padding columns [V, ldo). */
+int mdlm_subs_nll_bwd(const void* logits, int64_t ld, int dtype,
+                      const int64_t* xt, const int64_t* x0,
+                      const float* row_weight, void* dlogits_bf16, int64_t ldo,
+                      int64_t rows, int V, int mask_index, void* stream);
+
+/* out[0] = sum g^2 (two fixed-order stages; partial_1024 = 1024 floats). */
+int mdlm_grad_sumsq(const float* g, int64_t n, float* partial_1024, float* out,
+                    void* stream);
+
+/* clip_grad_norm_ (configs/config.yaml:69) + torch.optim.AdamW step
+ * (diffusion.py:449-459) + EMA (models/ema.py:44-49, diffusion.py:254-259) +
+ * bf16 copy of the new weights, on flat buffers.  g is scaled by grad_scale
+ * (1/world after a sum all-reduce) and by min(1, max_norm/(norm+1e-6)) with
+ * norm = grad_scale*sqrt(*sumsq) when sumsq != NULL and max_norm > 0.
+ * ema / w_bf16 may be NULL.  step is 1-based. */
+int mdlm_adamw_ema(float* p, const float* g, float* m, float* v, float* ema,
+                   void* w_bf16, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int64_t step,
+                   float ema_one_minus_decay, const float* sumsq, float max_norm,
+                   float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ F32, BF16 = 0, 1
 EPI_STORE, EPI_BIAS_GELU, EPI_GATE_RESIDUAL, EPI_QKV_ROTARY = 0, 1, 2, 3
 
 _vp, _i64, _i32, _u64, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_double
+_f32 = C.c_float
 
 # name -> argtypes; every function returns int.
 SIGNATURES = {
@@ -49,6 +50,22 @@ SIGNATURES = {
                      _vp, _vp],
   'mdlm_attn_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
   'mdlm_gemm_set_tile': [_i32],
+  # training step
+  'mdlm_attn_fwd_lse': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+  'mdlm_attn_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+  'mdlm_qkv_grad_pack': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+  'mdlm_ln_modulate_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i64, _i32, _vp],
+  'mdlm_colsum_reduce': [_vp, _vp, _i64, _i32, _i32, _vp],
+  'mdlm_colsum_bf16_partial': [_vp, _i64, _vp, _i64, _i32, _vp],
+  'mdlm_dropout_gate_residual_fwd': [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i64, _f32, _u64, _u64, _vp],
+  'mdlm_dropout_gate_residual_bwd': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i64, _f32, _u64, _u64, _vp],
+  'mdlm_gelu_fwd': [_vp, _vp, _i64, _vp],
+  'mdlm_gelu_bwd': [_vp, _vp, _vp, _i64, _vp],
+  'mdlm_transpose_bf16': [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+  'mdlm_embed_grad': [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
+  'mdlm_subs_nll_bwd': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
+  'mdlm_grad_sumsq': [_vp, _i64, _vp, _vp, _vp],
+  'mdlm_adamw_ema': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp, _f32, _f32, _vp],
   'mdlm_compact_active': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
 }
 

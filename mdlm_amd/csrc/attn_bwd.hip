@@ -1,0 +1,229 @@
+// Bidirectional attention backward for the DiT block (gfx950), head_dim 64:
+// the gradient of flash_attn_varlen_qkvpacked_func(qkv, ..., causal=False) at
+// models/dit.py:265-275, which the reference gets from flash-attn's autograd.
+//
+// Inputs: q, k head-major (n_seq,H,L,64), vt (n_seq,H,64,L) as written by the
+// QKV GEMM epilogue; o, do (n_seq*L, H*64) row-major; lse (n_seq,H,L) = log2-
+// domain log-sum-exp of the scaled scores from mdlm_attn_fwd_lse.
+// Outputs: dq, dk, dv head-major (n_seq,H,L,64) bf16.
+//
+// With P = exp2(S*sc - lse), S = Q K^T, sc = log2(e)/8, delta = rowsum(dO*O):
+//   dV = P^T dO,  dP = dO V^T,  dS = P * (dP - delta),
+//   dQ = dS K / 8,  dK = dS^T Q / 8.
+// Two kernels, no atomics (bitwise reproducible): one workgroup per 64-key
+// block accumulates dK/dV over the query blocks, one per 64-query block
+// accumulates dQ over the key blocks; P and dS are recomputed from the saved
+// lse.  Every matmul is v_mfma_f32_32x32x16_bf16 on 64x64 bf16 tiles staged in
+// LDS with both operands K-contiguous (a transposed copy is written at staging
+// time where the contraction runs over the tile's row index); P / dS go
+// through LDS once as bf16.  Four waves, one 32x32 output tile each.
+#include "common.h"
+
+namespace mdlm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BT = 64;            // tile edge
+constexpr int LDP = 72;           // LDS row stride in elements (144 B: 16-byte aligned, de-phased banks)
+constexpr int TILE_E = BT * LDP;  // elements per LDS tile
+
+// stage a 64x64 bf16 tile (row stride ld elements) into LDS row-major (dst)
+// and / or transposed (dst_t[col][row]); 256 threads
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int64_t ld,
+                                           bf16_t* dst, bf16_t* dst_t, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + i * 256;
+    const int row = id >> 3, ch = id & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)row * ld + ch * 8);
+    if (dst) *reinterpret_cast<uint4*>(dst + row * LDP + ch * 8) = v;
+    if (dst_t) {
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dst_t[(ch * 8 + 2 * k) * LDP + row] = (bf16_t)(w[k] & 0xffffu);
+        dst_t[(ch * 8 + 2 * k + 1) * LDP + row] = (bf16_t)(w[k] >> 16);
+      }
+    }
+  }
+}
+
+// acc[i][j] += sum_k A[i][k] * B[j][k], 32x32 tile, k < 64; A, B point at the
+// tile's first row in LDS.  acc[e]: i = 8*(e>>2) + 4*hh + (e&3), j = r.
+__device__ __forceinline__ void mma64(f32x16& acc, const bf16_t* A, const bf16_t* B, int r, int hh) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + r * LDP + ks * 16 + hh * 8);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + r * LDP + ks * 16 + hh * 8);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ int acc_row(int e, int hh) { return 8 * (e >> 2) + 4 * hh + (e & 3); }
+
+// delta[bh*L + l] = sum_d dO * O
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int64_t M, int H, int L) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (m, h, chunk)
+  const int ch = (int)(i & 7);
+  const int64_t mh = i >> 3;
+  float s = 0.f;
+  int64_t m = 0; int h = 0;
+  if (mh < M * H) {
+    h = (int)(mh % H); m = mh / H;
+    const int64_t off = m * ((int64_t)H * 64) + h * 64 + ch * 8;
+    const uint4 a = *reinterpret_cast<const uint4*>(o + off);
+    const uint4 b = *reinterpret_cast<const uint4*>(dout + off);
+    const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      s += __uint_as_float(aw[k] << 16) * __uint_as_float(bw[k] << 16) +
+           __uint_as_float(aw[k] & 0xffff0000u) * __uint_as_float(bw[k] & 0xffff0000u);
+  }
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+  if (mh < M * H && ch == 0) {
+    const int64_t seq = m / L;
+    delta[(seq * H + h) * L + (m - seq * L)] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ vt,
+    const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int H, int L) {
+  __shared__ __attribute__((aligned(16))) bf16_t sm[6 * TILE_E];
+  bf16_t* Ks = sm;                 // [key][d]
+  bf16_t* Vs = sm + TILE_E;        // [key][d]
+  bf16_t* Qs = sm + 2 * TILE_E;    // [q][d], then P^T [key][q]
+  bf16_t* dOs = sm + 3 * TILE_E;   // [q][d], then dS^T [key][q]
+  bf16_t* QTs = sm + 4 * TILE_E;   // [d][q]
+  bf16_t* dOTs = sm + 5 * TILE_E;  // [d][q]
+  const int kblocks = L / BT;
+  const int kb = blockIdx.x % kblocks;
+  const int bh = blockIdx.x / kblocks;
+  const int seq = bh / H, head = bh - seq * H;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int wa = wid >> 1, wb = wid & 1;  // tile row (key) / tile column (q or d)
+  const int key0 = kb * BT;
+  const int64_t D = (int64_t)H * 64;
+  stage_tile(k + ((int64_t)bh * L + key0) * 64, 64, Ks, nullptr, tid);
+  stage_tile(vt + (int64_t)bh * 64 * L + key0, L, nullptr, Vs, tid);
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 dk_acc = zero16, dv_acc = zero16;
+  const float sc = 0.125f * 1.4426950408889634f;
+  for (int qb = 0; qb < L / BT; ++qb) {
+    const int q0 = qb * BT;
+    stage_tile(q + ((int64_t)bh * L + q0) * 64, 64, Qs, QTs, tid);
+    stage_tile(dout + ((int64_t)seq * L + q0) * D + head * 64, D, dOs, dOTs, tid);
+    const float lse_q = lse[(int64_t)bh * L + q0 + wb * 32 + r];
+    const float del_q = delta[(int64_t)bh * L + q0 + wb * 32 + r];
+    __syncthreads();
+    f32x16 st = zero16, dpt = zero16;   // S^T, dP^T tiles [key (rows), q (cols)]
+    mma64(st, Ks + wa * 32 * LDP, Qs + wb * 32 * LDP, r, hh);
+    mma64(dpt, Vs + wa * 32 * LDP, dOs + wb * 32 * LDP, r, hh);
+    __syncthreads();  // every wave is done reading Qs / dOs
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float p = __builtin_amdgcn_exp2f(st[e] * sc - lse_q);
+      const float ds = p * (dpt[e] - del_q);
+      const int key = wa * 32 + acc_row(e, hh);
+      Qs[key * LDP + wb * 32 + r] = f32_to_bf16(p);
+      dOs[key * LDP + wb * 32 + r] = f32_to_bf16(ds);
+    }
+    __syncthreads();
+    // dV[key, d] += P^T[key, :] . dO[:, d];  dK[key, d] += dS^T[key, :] . Q[:, d]
+    mma64(dv_acc, Qs + wa * 32 * LDP, dOTs + wb * 32 * LDP, r, hh);
+    mma64(dk_acc, dOs + wa * 32 * LDP, QTs + wb * 32 * LDP, r, hh);
+    __syncthreads();
+  }
+  bf16_t* dkp = dk + ((int64_t)bh * L + key0 + wa * 32) * 64 + wb * 32 + r;
+  bf16_t* dvp = dv + ((int64_t)bh * L + key0 + wa * 32) * 64 + wb * 32 + r;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = acc_row(e, hh);
+    dkp[row * 64] = f32_to_bf16(dk_acc[e] * 0.125f);
+    dvp[row * 64] = f32_to_bf16(dv_acc[e]);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ vt,
+    const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
+    bf16_t* __restrict__ dq, int H, int L) {
+  __shared__ __attribute__((aligned(16))) bf16_t sm[6 * TILE_E];
+  __shared__ float lse_s[BT], del_s[BT];
+  bf16_t* Qs = sm;                // [q][d]
+  bf16_t* dOs = sm + TILE_E;      // [q][d]
+  bf16_t* Ks = sm + 2 * TILE_E;   // [key][d]
+  bf16_t* Vs = sm + 3 * TILE_E;   // [key][d]
+  bf16_t* KTs = sm + 4 * TILE_E;  // [d][key]
+  bf16_t* dSs = sm + 5 * TILE_E;  // [q][key]
+  const int qblocks = L / BT;
+  const int qb = blockIdx.x % qblocks;
+  const int bh = blockIdx.x / qblocks;
+  const int seq = bh / H, head = bh - seq * H;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int wa = wid >> 1, wb = wid & 1;  // tile row (q) / tile column (key or d)
+  const int q0 = qb * BT;
+  const int64_t D = (int64_t)H * 64;
+  stage_tile(q + ((int64_t)bh * L + q0) * 64, 64, Qs, nullptr, tid);
+  stage_tile(dout + ((int64_t)seq * L + q0) * D + head * 64, D, dOs, nullptr, tid);
+  if (tid < BT) {
+    lse_s[tid] = lse[(int64_t)bh * L + q0 + tid];
+    del_s[tid] = delta[(int64_t)bh * L + q0 + tid];
+  }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 dq_acc = zero16;
+  const float sc = 0.125f * 1.4426950408889634f;
+  for (int kb = 0; kb < L / BT; ++kb) {
+    const int key0 = kb * BT;
+    stage_tile(k + ((int64_t)bh * L + key0) * 64, 64, Ks, KTs, tid);
+    stage_tile(vt + (int64_t)bh * 64 * L + key0, L, nullptr, Vs, tid);
+    __syncthreads();
+    f32x16 s = zero16, dp = zero16;   // S, dP tiles [q (rows), key (cols)]
+    mma64(s, Qs + wa * 32 * LDP, Ks + wb * 32 * LDP, r, hh);
+    mma64(dp, dOs + wa * 32 * LDP, Vs + wb * 32 * LDP, r, hh);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int qi = wa * 32 + acc_row(e, hh);
+      const float p = __builtin_amdgcn_exp2f(s[e] * sc - lse_s[qi]);
+      dSs[qi * LDP + wb * 32 + r] = f32_to_bf16(p * (dp[e] - del_s[qi]));
+    }
+    __syncthreads();
+    // dQ[q, d] += dS[q, :] . K[:, d]
+    mma64(dq_acc, dSs + wa * 32 * LDP, KTs + wb * 32 * LDP, r, hh);
+    __syncthreads();
+  }
+  bf16_t* dqp = dq + ((int64_t)bh * L + q0 + wa * 32) * 64 + wb * 32 + r;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) dqp[acc_row(e, hh) * 64] = f32_to_bf16(dq_acc[e] * 0.125f);
+}
+
+}  // namespace mdlm
+
+using namespace mdlm;
+
+extern "C" int mdlm_attn_bwd(const void* q, const void* k, const void* vt, const void* o,
+                             const void* dout, const float* lse, float* delta_ws,
+                             void* dq, void* dk, void* dv, int n_seq, int H, int L,
+                             void* stream) {
+  if (n_seq == 0) return 0;
+  MDLM_CHECK_ARG(q && k && vt && o && dout && lse && delta_ws && dq && dk && dv, "attn_bwd: null pointer");
+  MDLM_CHECK_ARG(n_seq > 0 && H > 0 && L > 0 && L % BT == 0, "attn_bwd: L=%d must be a multiple of %d", L, BT);
+  MDLM_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+                 "attn_bwd: buffers must be 16-byte aligned");
+  const int64_t M = (int64_t)n_seq * L;
+  const int64_t blocks = (int64_t)n_seq * H * (L / BT);
+  MDLM_CHECK_ARG(blocks < (1ll << 31) && M * H * 8 / 256 < (1ll << 31), "attn_bwd: too many blocks");
+  hipStream_t s = (hipStream_t)stream;
+  attn_delta_kernel<<<(unsigned)((M * H * 8 + 255) / 256), 256, 0, s>>>((const bf16_t*)o, (const bf16_t*)dout, delta_ws, M, H, L);
+  attn_bwd_dkdv_kernel<<<(unsigned)blocks, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (const bf16_t*)dout,
+                                                        lse, delta_ws, (bf16_t*)dk, (bf16_t*)dv, H, L);
+  attn_bwd_dq_kernel<<<(unsigned)blocks, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (const bf16_t*)dout,
+                                                      lse, delta_ws, (bf16_t*)dq, H, L);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}

@@ -43,7 +43,7 @@ template <int QT>
 __global__ __launch_bounds__(AT, 2) void attn_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
     const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, int H, int L,
-    const int32_t* __restrict__ n_seq_dev) {
+    const int32_t* __restrict__ n_seq_dev, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE];  // K0 K1 V0 V1
   constexpr int QBQ = QB * QT;           // query rows per workgroup
   const int qblocks = L / QBQ;
@@ -227,6 +227,8 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_kernel(
   for (int t = 0; t < QT; ++t) {
     const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32);
     const float inv = 1.f / l_tot;
+    // training: log2-domain log-sum-exp of the scaled scores, read by the backward
+    if (lse && hh == 0) lse[(int64_t)bh * L + q0 + t * 32 + r] = m_run[t] + __log2f(l_tot);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -253,9 +255,9 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_kernel(
 
 using namespace mdlm;
 
-extern "C" int mdlm_attn_fwd(const void* q, const void* k, const void* vt,
-                             void* out, int n_seq, int H, int L,
-                             const int32_t* n_seq_dev, void* stream) {
+static int attn_fwd_launch(const void* q, const void* k, const void* vt,
+                           void* out, int n_seq, int H, int L,
+                           const int32_t* n_seq_dev, float* lse, void* stream) {
   if (n_seq == 0) return 0;
   MDLM_CHECK_ARG(q && k && vt && out, "attn_fwd: null pointer");
   MDLM_CHECK_ARG(n_seq >= 0 && H > 0 && L > 0 && L % QB == 0, "attn_fwd: L=%d must be a multiple of %d", L, QB);
@@ -266,10 +268,23 @@ extern "C" int mdlm_attn_fwd(const void* q, const void* k, const void* vt,
   MDLM_CHECK_ARG(blocks < (1ll << 31), "attn_fwd: too many blocks");
   if (qt == 2)
     attn_fwd_kernel<2><<<(unsigned)blocks, AT, 0, (hipStream_t)stream>>>(
-      (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, L, n_seq_dev);
+      (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, L, n_seq_dev, lse);
   else
     attn_fwd_kernel<1><<<(unsigned)blocks, AT, 0, (hipStream_t)stream>>>(
-      (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, L, n_seq_dev);
+      (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, L, n_seq_dev, lse);
   MDLM_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int mdlm_attn_fwd(const void* q, const void* k, const void* vt,
+                             void* out, int n_seq, int H, int L,
+                             const int32_t* n_seq_dev, void* stream) {
+  return attn_fwd_launch(q, k, vt, out, n_seq, H, L, n_seq_dev, nullptr, stream);
+}
+
+extern "C" int mdlm_attn_fwd_lse(const void* q, const void* k, const void* vt,
+                                 void* out, float* lse, int n_seq, int H, int L,
+                                 void* stream) {
+  MDLM_CHECK_ARG(lse || n_seq == 0, "attn_fwd_lse: null lse");
+  return attn_fwd_launch(q, k, vt, out, n_seq, H, L, nullptr, lse, stream);
 }

@@ -367,3 +367,129 @@ def masked_row_map(x, active, n_active, L, mask_index, gather, scatter, n_out,
 def gemm_set_tile(force_small):
   """Test hook: force the 128x128 GEMM tile (see mdlm_gemm_set_tile)."""
   call('mdlm_gemm_set_tile', int(force_small))
+
+
+# ------------------------------------------------------- training step (f-3)
+def attn_fwd_lse(q, k, vt, out, lse, n_seq, H, L):
+  call('mdlm_attn_fwd_lse', q.data_ptr(), k.data_ptr(), vt.data_ptr(),
+       out.data_ptr(), lse.data_ptr(), int(n_seq), int(H), int(L), _stream())
+  return out
+
+
+def attn_bwd(q, k, vt, o, dout, lse, delta_ws, dq, dk, dv, n_seq, H, L):
+  call('mdlm_attn_bwd', q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(),
+       dout.data_ptr(), lse.data_ptr(), delta_ws.data_ptr(), dq.data_ptr(),
+       dk.data_ptr(), dv.data_ptr(), int(n_seq), int(H), int(L), _stream())
+
+
+def qkv_grad_pack(dq, dk, dv, cos, sin, dqkv, n_seq, H, L):
+  call('mdlm_qkv_grad_pack', dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+       cos.data_ptr(), sin.data_ptr(), dqkv.data_ptr(), int(n_seq), int(H),
+       int(L), _stream())
+  return dqkv
+
+
+def ln_modulate_bwd(dh, x, ln_w, scale, dx_inout, partial, rows_per_mod, n_mod,
+                    mod_ld, accumulate=True):
+  rows, D = x.shape
+  call('mdlm_ln_modulate_bwd', dh.data_ptr(), x.data_ptr(), ln_w.data_ptr(),
+       scale.data_ptr(), dx_inout.data_ptr(), partial.data_ptr(), int(rows),
+       int(D), int(rows_per_mod), int(n_mod), int(mod_ld), int(bool(accumulate)),
+       _stream())
+
+
+def colsum_reduce(partial, out, C, per_out, n_out):
+  call('mdlm_colsum_reduce', partial.data_ptr(), out.data_ptr(), int(C),
+       int(per_out), int(n_out), _stream())
+  return out
+
+
+def colsum_bf16(x, partial=None, out=None):
+  """Column sums (fp32) of a 2-D bf16 matrix, two fixed-order stages."""
+  rows, N = x.shape
+  nblk = (rows + 127) // 128
+  if partial is None:
+    partial = torch.empty(nblk, N, dtype=torch.float32, device=x.device)
+  if out is None:
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+  call('mdlm_colsum_bf16_partial', x.data_ptr(), x.stride(0), partial.data_ptr(),
+       int(rows), int(N), _stream())
+  return colsum_reduce(partial, out, N, nblk, 1)
+
+
+def dropout_gate_residual_fwd(y, gate, residual, out, rows_per_mod, n_mod, mod_ld,
+                              p, seed, offset):
+  rows, D = y.shape
+  call('mdlm_dropout_gate_residual_fwd', y.data_ptr(), gate.data_ptr(),
+       residual.data_ptr(), out.data_ptr(), int(rows), int(D), int(rows_per_mod),
+       int(n_mod), int(mod_ld), float(p), int(seed), int(offset), _stream())
+  return out
+
+
+def dropout_gate_residual_bwd(dout, y, gate, dy, partial, rows_per_mod, n_mod,
+                              mod_ld, p, seed, offset):
+  rows, D = y.shape
+  call('mdlm_dropout_gate_residual_bwd', dout.data_ptr(), y.data_ptr(),
+       gate.data_ptr(), dy.data_ptr(), partial.data_ptr(), int(rows), int(D),
+       int(rows_per_mod), int(n_mod), int(mod_ld), float(p), int(seed),
+       int(offset), _stream())
+
+
+def gelu_fwd(pre, act):
+  call('mdlm_gelu_fwd', pre.data_ptr(), act.data_ptr(), pre.numel(), _stream())
+  return act
+
+
+def gelu_bwd(dact, pre, dpre):
+  call('mdlm_gelu_bwd', dact.data_ptr(), pre.data_ptr(), dpre.data_ptr(),
+       pre.numel(), _stream())
+  return dpre
+
+
+def transpose_bf16(x, out=None, ld_out=None):
+  """(R, C) or (batch, R, C) bf16 -> (C, R) / (batch, C, R); the input may have
+  a padded leading dimension (stride(-2) >= C)."""
+  if x.dim() == 2:
+    R, C = x.shape
+    batch, bs_in = 1, 0
+  else:
+    batch, R, C = x.shape
+    bs_in = x.stride(0)
+  if out is None:
+    shape = (C, R) if x.dim() == 2 else (batch, C, R)
+    out = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
+  ld_o = out.stride(-2) if ld_out is None else ld_out
+  bs_out = out.stride(0) if out.dim() == 3 else 0
+  call('mdlm_transpose_bf16', x.data_ptr(), x.stride(-2), int(bs_in),
+       out.data_ptr(), int(ld_o), int(bs_out), int(R), int(C), int(batch),
+       _stream())
+  return out
+
+
+def embed_grad(dx, idx, dtable):
+  rows, D = dx.shape
+  call('mdlm_embed_grad', dx.data_ptr(), idx.data_ptr(), dtable.data_ptr(),
+       int(rows), int(D), int(dtable.shape[0]), _stream())
+
+
+def subs_nll_bwd(logits2d, xt, x0, row_weight, dlogits2d, V, mask_index):
+  """logits2d / dlogits2d: (rows, >=V) views with padded leading dimension."""
+  rows = logits2d.shape[0]
+  call('mdlm_subs_nll_bwd', logits2d.data_ptr(), logits2d.stride(0),
+       _DT[logits2d.dtype], xt.data_ptr(), x0.data_ptr(), row_weight.data_ptr(),
+       dlogits2d.data_ptr(), dlogits2d.stride(0), int(rows), int(V),
+       int(mask_index), _stream())
+
+
+def grad_sumsq(g, partial, out):
+  call('mdlm_grad_sumsq', g.data_ptr(), g.numel(), partial.data_ptr(),
+       out.data_ptr(), _stream())
+  return out
+
+
+def adamw_ema(p, g, m, v, ema, w16, lr, beta1, beta2, eps, weight_decay, step,
+              ema_one_minus_decay, sumsq=None, max_norm=0.0, grad_scale=1.0):
+  call('mdlm_adamw_ema', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
+       _p(ema), _p(w16), p.numel(), float(lr), float(beta1), float(beta2),
+       float(eps), float(weight_decay), int(step), float(ema_one_minus_decay),
+       _p(sumsq), float(max_norm), float(grad_scale), _stream())
