@@ -1,0 +1,402 @@
+"""Training step of the DiT/SUBS model on MI355X kernels.
+
+Mirrors the reference's `training_step` (diffusion.py:390-397) -> `_loss`
+(896-916) with the backbone in train mode (dropout 0.1 inside
+bias_dropout_add_scale, dit.py:20-34), Lightning's `gradient_clip_val: 1.0`
+(configs/config.yaml:69), `torch.optim.AdamW` (diffusion.py:449-459), the
+constant-with-warmup schedule (configs/lr_scheduler/constant_warmup.yaml) and
+the EMA update after every optimizer step (diffusion.py:254-259,
+models/ema.py:29-49).  Where the reference relies on torch autograd, every
+backward here is a hand-written HIP kernel (mdlm_amd/csrc/train_ops.hip,
+attn_bwd.hip) or mdlm_gemm_bf16 on transposed operands.  The only autograd
+left is the conditioning network (sigma_map + adaLN Linear on a (n_mod, 128)
+vector: a few kFLOP), which receives d(mod) from the kernels.
+
+Memory layout: every parameter is a view of ONE flat fp32 buffer; gradients,
+Adam moments, EMA shadow and the bf16 GEMM copies are flat buffers with the
+same offsets, so clip + AdamW + EMA + bf16 refresh is one launch over 170 M
+elements and a DDP bucket is a contiguous slice.  Data parallelism: one
+process per GPU; the gradient slice of a block is all-reduced (RCCL over xGMI,
+sum; the 1/world scale is folded into the optimizer kernel) on a side stream as
+soon as that block's backward has finished, overlapping the remaining blocks.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import EPI_QKV_ROTARY, EPI_STORE
+
+_ALIGN = 64  # elements: every parameter view starts 256-byte aligned
+
+
+def constant_warmup_lr(base_lr, step, num_warmup_steps):
+  """transformers.get_constant_schedule_with_warmup: lr of optimizer step
+  number `step` (0-based)."""
+  if step < num_warmup_steps:
+    return base_lr * float(step) / float(max(1.0, num_warmup_steps))
+  return base_lr
+
+
+class GradBuckets:
+  """Contiguous slices of the flat gradient buffer, all-reduced asynchronously
+  (sum) in the order their backward finishes.  Works on any device/backend
+  (RCCL on the GPU, gloo in the CPU tests)."""
+
+  def __init__(self, flat, slices, group=None):
+    self.flat, self.slices, self.group = flat, slices, group
+    self.work = []
+    self.stream = torch.cuda.Stream() if flat.is_cuda else None
+
+  @property
+  def enabled(self):
+    return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+  def launch(self, i):
+    if not self.enabled:
+      return
+    a, b = self.slices[i]
+    if b <= a:
+      return
+    if self.stream is not None:
+      self.stream.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(self.stream):
+        self.work.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM,
+                                         group=self.group, async_op=True))
+    else:
+      self.work.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM,
+                                       group=self.group, async_op=True))
+
+  def wait_all(self):
+    for w in self.work:
+      w.wait()
+    self.work = []
+    if self.stream is not None:
+      torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class Trainer:
+  def __init__(self, model, lr=None, betas=None, eps=None, weight_decay=None,
+               max_norm=1.0, num_warmup_steps=2500, dropout=None, group=None):
+    cfg = model.config
+    bb = model.backbone
+    dev = bb.vocab_embed.embedding.device
+    if dev.type != 'cuda':
+      raise RuntimeError('mdlm_amd.Trainer needs the model on a ROCm device; '
+                         'there is no CPU fallback')
+    self.model, self.bb, self.dev = model, bb, dev
+    self.lr = cfg.optim.lr if lr is None else lr
+    self.betas = (cfg.optim.beta1, cfg.optim.beta2) if betas is None else betas
+    self.eps = cfg.optim.eps if eps is None else eps
+    self.weight_decay = cfg.optim.weight_decay if weight_decay is None else weight_decay
+    self.max_norm = max_norm
+    self.num_warmup_steps = num_warmup_steps
+    self.p_drop = float(bb.blocks[0].dropout if dropout is None else dropout)
+    self.ema_decay = float(cfg.training.ema)
+    self.step_count = 0
+    self.group = group
+    self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    # ---- flat buffers ------------------------------------------------------
+    named = list(bb.named_parameters())
+    self.names = [n for n, _ in named]
+    self.offsets, off = {}, 0
+    for n, p in named:
+      self.offsets[n] = (off, p.numel(), tuple(p.shape))
+      off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+    self.n_flat = off
+    z = lambda dt=torch.float32: torch.zeros(off, dtype=dt, device=dev)
+    self.P, self.G, self.M1, self.M2 = z(), z(), z(), z()
+    self.W16 = z(torch.bfloat16)
+    for n, p in named:
+      v = self._view(self.P, n)
+      v.copy_(p.data)
+      p.data = v
+      p.grad = self._view(self.G, n)
+    self.W16.copy_(self.P)
+    self.E = None
+    if self.ema_decay > 0:
+      self.E = self.P.clone()
+      if getattr(model, 'ema', None):
+        model.ema.shadow_params = [self._view(self.E, n) for n in self.names]
+    bb.refresh()
+    # DDP buckets in the order the backward completes them: output layer,
+    # blocks L-1..0, then everything before block 0 (embedding, sigma_map)
+    def span(prefix):
+      ks = [n for n in self.names if n.startswith(prefix)]
+      a = self.offsets[ks[0]][0]
+      o, n_, _ = self.offsets[ks[-1]]
+      return a, (o + n_ + _ALIGN - 1) // _ALIGN * _ALIGN
+    self.bucket_ids = {}
+    slices = [span('output_layer.')]
+    for i in reversed(range(bb.n_blocks)):
+      self.bucket_ids[i] = len(slices)
+      slices.append(span(f'blocks.{i}.'))
+    slices.append((0, span('blocks.0.')[0]))
+    self.buckets = GradBuckets(self.G, slices, group)
+    self._ws = None
+    self._sumsq = torch.zeros(1, device=dev)
+    self._sumsq_part = torch.empty(1024, device=dev)
+    self.last_grad_norm = None
+
+  # ---------------------------------------------------------------- helpers
+  def _view(self, flat, name):
+    o, n, shape = self.offsets[name]
+    return flat[o:o + n].view(shape)
+
+  def grads(self):
+    return {n: self._view(self.G, n) for n in self.names}
+
+  def ema_state_dict(self):
+    """models/ema.py:89-92 layout."""
+    return dict(decay=self.ema_decay, num_updates=self.step_count,
+                shadow_params=[self._view(self.E, n) for n in self.names])
+
+  def _workspace(self, B, L):
+    key = (B, L)
+    if self._ws is not None and self._ws['key'] == key:
+      return self._ws
+    bb, dev = self.bb, self.dev
+    D, H, V = bb.hidden, bb.n_heads, bb.vocab_size
+    M, Vp = B * L, ops.padded_vocab(V)
+    bf = torch.bfloat16
+    e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)
+    blocks = []
+    for _ in range(bb.n_blocks):
+      blocks.append(dict(
+        x_in=e(M, D, dt=torch.float32), h1=e(M, D), qkv=e(3 * M * D), ao=e(M, D),
+        lse=e(B * H * L, dt=torch.float32), y1=e(M, D), x_mid=e(M, D, dt=torch.float32),
+        h2=e(M, D), pre=e(M, 4 * D), act=e(M, 4 * D), y2=e(M, D), drop=[0, 0]))
+    inv_freq = bb.rotary_emb.inv_freq.float()
+    fr = torch.einsum('i,j->ij', torch.arange(L, device=dev).float(), inv_freq)
+    nblk = M // 32
+    self._ws = dict(
+      key=key, blocks=blocks, x_last=e(M, D, dt=torch.float32), hf=e(M, D),
+      logits=torch.zeros(M, Vp, dtype=bf, device=dev), dlogits=e(M, Vp),
+      cos=fr.cos().to(bf).float().contiguous(), sin=fr.sin().to(bf).float().contiguous(),
+      dx=e(M, D, dt=torch.float32), d_md=e(M, D), d_m4=e(M, 4 * D), d_m4b=e(M, 4 * D),
+      d_qkv=e(M, 3 * D), dq=e(M * D), dk=e(M * D), dv=e(M * D),
+      delta=e(B * H * L, dt=torch.float32),
+      tA=e(max(Vp, 4 * D) * M), tB=e(4 * D * M), wT=e(max(Vp * D, 4 * D * D)),
+      wvT=torch.zeros(D, Vp, dtype=bf, device=dev),
+      dwv=e(Vp, D, dt=torch.float32),
+      part3=e(nblk, 3, D, dt=torch.float32), part1=e(nblk, D, dt=torch.float32),
+      partc=e((M + 127) // 128, max(Vp, 4 * D), dt=torch.float32))
+    return self._ws
+
+  def _w16(self, name):
+    return self._view(self.W16, name)
+
+  def _p32(self, name):
+    return self._view(self.P, name)
+
+  def _g(self, name):
+    return self._view(self.G, name)
+
+  def _conditioning(self, n_mod, sigma):
+    """c = silu(sigma_map(timestep_embedding(sigma))) and the adaLN vectors
+    (dit.py:361, 249-250, 318) in fp32 torch autograd (tiny)."""
+    bb = self.bb
+    te = ops.timestep_embedding(sigma.float().contiguous(),
+                                bb.sigma_map.frequency_embedding_size)
+    m = bb.sigma_map.mlp
+    c = F.silu(F.linear(F.silu(F.linear(te, m[0].weight, m[0].bias)), m[2].weight, m[2].bias))
+    mods = [F.linear(c, b.adaLN_modulation.weight, b.adaLN_modulation.bias) for b in bb.blocks]
+    mods.append(F.linear(c, bb.output_layer.adaLN_modulation.weight,
+                         bb.output_layer.adaLN_modulation.bias))
+    return mods
+
+  def _transpose(self, x, buf):
+    R, C = x.shape
+    out = buf[:R * C].view(C, R)
+    return ops.transpose_bf16(x, out=out)
+
+  def _wt(self, name, ws):
+    w = self._w16(name)
+    return self._transpose(w, ws['wT'])
+
+  def _linear_bwd(self, dy, a, wname, bname, ws, da_out):
+    """y = a W^T (+ b): G[W] = dy^T a, G[b] = colsum(dy), da = dy W."""
+    dyT = self._transpose(dy, ws['tA'])
+    aT = self._transpose(a, ws['tB'])
+    ops.gemm_bf16(dyT, aT, self._g(wname), EPI_STORE)
+    if bname is not None:
+      ops.colsum_bf16(dy, partial=ws['partc'], out=self._g(bname))
+    if da_out is not None:
+      ops.gemm_bf16(dy, self._wt(wname, ws), da_out, EPI_STORE)
+    return da_out
+
+  # ----------------------------------------------------------- forward/backward
+  def forward_backward(self, x0, attention_mask=None, t=None, u_xt=None):
+    """Loss of one micro-batch and its gradients into the flat buffer G
+    (overwritten).  Returns (token_nll device scalar, nlls (B, L))."""
+    model, bb = self.model, self.bb
+    B, L = x0.shape
+    D, H, V = bb.hidden, bb.n_heads, bb.vocab_size
+    M = B * L
+    if M % 128 or L % 64 or D % 128:
+      raise ValueError('Trainer: B*L must be a multiple of 128, L of 64, hidden of 128')
+    ws = self._workspace(B, L)
+    if attention_mask is None:
+      attention_mask = torch.ones(B, L, dtype=torch.float32, device=self.dev)
+    attention_mask = attention_mask.float()
+    # ---- noising (diffusion.py:847-869) -------------------------------------
+    if t is None:
+      t = model._sample_t(B, self.dev)
+    sigma, dsigma = model.noise(t)
+    move_chance = 1 - torch.exp(-sigma[:, None])
+    xt = model.q_xt(x0, move_chance, u=u_xt)
+    sig_in = model._process_sigma(sigma[:, None])
+    n_mod = B if model.time_conditioning else 1
+    with torch.enable_grad():
+      mods = self._conditioning(n_mod, sig_in[:n_mod])
+    md = [m.detach() for m in mods]
+    ld6, ld2 = 6 * D, 2 * D
+    p = self.p_drop
+    seed = model._rng_seed
+    # ---- forward, activations saved -----------------------------------------
+    x = ws['blocks'][0]['x_in']
+    ops.embed_rows(self._p32('vocab_embed.embedding'), xt, x)
+    for i, a in enumerate(ws['blocks']):
+      pre_ = f'blocks.{i}.'
+      mod = md[i]
+      x = a['x_in']
+      ops.ln_modulate(x, self._p32(pre_ + 'norm1.weight'), mod[:, 0:D], mod[:, D:2 * D],
+                      a['h1'], L, n_mod, ld6)
+      ops.gemm_bf16(a['h1'], self._w16(pre_ + 'attn_qkv.weight'), a['qkv'], EPI_QKV_ROTARY,
+                    rows_per_mod=L, rot_cos=ws['cos'], rot_sin=ws['sin'], n_heads=H, ldc=0, M=M)
+      q_, k_, vt_ = a['qkv'][:M * D], a['qkv'][M * D:2 * M * D], a['qkv'][2 * M * D:]
+      ops.attn_fwd_lse(q_, k_, vt_, a['ao'], a['lse'], B, H, L)
+      ops.gemm_bf16(a['ao'], self._w16(pre_ + 'attn_out.weight'), a['y1'], EPI_STORE)
+      a['drop'][0] = model._draw(M * D // 4)[1]
+      ops.dropout_gate_residual_fwd(a['y1'], mod[:, 2 * D:3 * D], x, a['x_mid'], L, n_mod,
+                                    ld6, p, seed, a['drop'][0])
+      ops.ln_modulate(a['x_mid'], self._p32(pre_ + 'norm2.weight'), mod[:, 3 * D:4 * D],
+                      mod[:, 4 * D:5 * D], a['h2'], L, n_mod, ld6)
+      ops.gemm_bf16(a['h2'], self._w16(pre_ + 'mlp.0.weight'), a['pre'], EPI_STORE,
+                    bias=self._p32(pre_ + 'mlp.0.bias'))
+      ops.gelu_fwd(a['pre'], a['act'])
+      ops.gemm_bf16(a['act'], self._w16(pre_ + 'mlp.2.weight'), a['y2'], EPI_STORE,
+                    bias=self._p32(pre_ + 'mlp.2.bias'))
+      a['drop'][1] = model._draw(M * D // 4)[1]
+      x_next = ws['blocks'][i + 1]['x_in'] if i + 1 < bb.n_blocks else ws['x_last']
+      ops.dropout_gate_residual_fwd(a['y2'], mod[:, 5 * D:6 * D], a['x_mid'], x_next, L, n_mod,
+                                    ld6, p, seed, a['drop'][1])
+    modf = md[-1]
+    ops.ln_modulate(ws['x_last'], self._p32('output_layer.norm_final.weight'), modf[:, 0:D],
+                    modf[:, D:2 * D], ws['hf'], L, n_mod, ld2)
+    logits = ws['logits'][:, :V]
+    ops.gemm_bf16(ws['hf'], self._w16('output_layer.linear.weight'), logits, EPI_STORE,
+                  bias=self._p32('output_layer.linear.bias'), ldc=ws['logits'].stride(0))
+    # ---- loss (diffusion.py:884-916) ------------------------------------------
+    weight = dsigma / torch.expm1(sigma)
+    nlls = ops.subs_nll(logits.view(B, L, V), xt, x0, weight, model.mask_index,
+                        attn_mask=attention_mask)
+    sums = ops.nll_sums(nlls, attention_mask)
+    token_nll = (sums[0] / sums[1]).float()
+    row_w = (weight[:, None] * attention_mask / attention_mask.sum()).reshape(-1).contiguous()
+    # ---- backward --------------------------------------------------------------
+    self.G.zero_()
+    dl = ws['dlogits'][:, :V]
+    ops.subs_nll_bwd(logits, xt.view(-1), x0.reshape(-1).contiguous(), row_w, dl, V,
+                     model.mask_index)
+    # output layer: logits = hf Wv^T + bv (rows of dWv beyond V land in a scratch)
+    ops.colsum_bf16(dl, partial=ws['partc'], out=self._g('output_layer.linear.bias'))
+    dlT = self._transpose(ws['dlogits'], ws['tA'])
+    hfT = self._transpose(ws['hf'], ws['tB'])
+    ops.gemm_bf16(dlT, hfT, ws['dwv'], EPI_STORE)
+    self._g('output_layer.linear.weight').copy_(ws['dwv'][:V])
+    ops.transpose_bf16(self._w16('output_layer.linear.weight'), out=ws['wvT'][:, :V],
+                       ld_out=ws['wvT'].stride(0))
+    ops.gemm_bf16(ws['dlogits'], ws['wvT'], ws['d_md'], EPI_STORE)
+    dx = ws['dx']
+    nb32 = L // 32
+    red3 = torch.empty(n_mod, 3, D, device=self.dev)
+    red1 = torch.empty(n_mod, D, device=self.dev)
+    ops.ln_modulate_bwd(ws['d_md'], ws['x_last'], self._p32('output_layer.norm_final.weight'),
+                        modf[:, D:2 * D], dx, ws['part3'], L, n_mod, ld2, accumulate=False)
+    ops.colsum_reduce(ws['part3'], red3, 3 * D, (M // 32) // n_mod, n_mod)
+    self._g('output_layer.norm_final.weight').copy_(red3[:, 0].sum(0))
+    dmods = [None] * (bb.n_blocks + 1)
+    dmods[-1] = torch.cat([red3[:, 2], red3[:, 1]], dim=1)
+    with torch.enable_grad():
+      torch.autograd.backward([mods[-1]], [dmods[-1]], retain_graph=True)
+    self.buckets.launch(0)
+    for i in reversed(range(bb.n_blocks)):
+      a = ws['blocks'][i]
+      pre_ = f'blocks.{i}.'
+      mod = md[i]
+      dm = torch.empty(n_mod, 6 * D, device=self.dev)
+      # x_out = x_mid + gate_mlp * dropout(y2)
+      ops.dropout_gate_residual_bwd(dx, a['y2'], mod[:, 5 * D:6 * D], ws['d_md'], ws['part1'],
+                                    L, n_mod, ld6, p, seed, a['drop'][1])
+      ops.colsum_reduce(ws['part1'], red1, D, (M // 32) // n_mod, n_mod)
+      dm[:, 5 * D:] = red1
+      self._linear_bwd(ws['d_md'], a['act'], pre_ + 'mlp.2.weight', pre_ + 'mlp.2.bias', ws, ws['d_m4'])
+      ops.gelu_bwd(ws['d_m4'], a['pre'], ws['d_m4b'])
+      self._linear_bwd(ws['d_m4b'], a['h2'], pre_ + 'mlp.0.weight', pre_ + 'mlp.0.bias', ws, ws['d_md'])
+      ops.ln_modulate_bwd(ws['d_md'], a['x_mid'], self._p32(pre_ + 'norm2.weight'),
+                          mod[:, 4 * D:5 * D], dx, ws['part3'], L, n_mod, ld6, accumulate=True)
+      ops.colsum_reduce(ws['part3'], red3, 3 * D, (M // 32) // n_mod, n_mod)
+      self._g(pre_ + 'norm2.weight').copy_(red3[:, 0].sum(0))
+      dm[:, 3 * D:4 * D] = red3[:, 2]
+      dm[:, 4 * D:5 * D] = red3[:, 1]
+      # x_mid = x_in + gate_msa * dropout(y1)
+      ops.dropout_gate_residual_bwd(dx, a['y1'], mod[:, 2 * D:3 * D], ws['d_md'], ws['part1'],
+                                    L, n_mod, ld6, p, seed, a['drop'][0])
+      ops.colsum_reduce(ws['part1'], red1, D, (M // 32) // n_mod, n_mod)
+      dm[:, 2 * D:3 * D] = red1
+      dao = ws['d_m4'].view(-1)[:M * D].view(M, D)
+      self._linear_bwd(ws['d_md'], a['ao'], pre_ + 'attn_out.weight', None, ws, dao)
+      q_, k_, vt_ = a['qkv'][:M * D], a['qkv'][M * D:2 * M * D], a['qkv'][2 * M * D:]
+      ops.attn_bwd(q_, k_, vt_, a['ao'], dao, a['lse'], ws['delta'], ws['dq'], ws['dk'],
+                   ws['dv'], B, H, L)
+      ops.qkv_grad_pack(ws['dq'], ws['dk'], ws['dv'], ws['cos'], ws['sin'], ws['d_qkv'], B, H, L)
+      self._linear_bwd(ws['d_qkv'], a['h1'], pre_ + 'attn_qkv.weight', None, ws, ws['d_md'])
+      ops.ln_modulate_bwd(ws['d_md'], a['x_in'], self._p32(pre_ + 'norm1.weight'),
+                          mod[:, D:2 * D], dx, ws['part3'], L, n_mod, ld6, accumulate=True)
+      ops.colsum_reduce(ws['part3'], red3, 3 * D, (M // 32) // n_mod, n_mod)
+      self._g(pre_ + 'norm1.weight').copy_(red3[:, 0].sum(0))
+      dm[:, 0:D] = red3[:, 2]
+      dm[:, D:2 * D] = red3[:, 1]
+      dmods[i] = dm
+      with torch.enable_grad():
+        torch.autograd.backward([mods[i]], [dm], retain_graph=i > 0)
+      self.buckets.launch(self.bucket_ids[i])
+    ops.embed_grad(dx, xt.view(-1), self._g('vocab_embed.embedding'))
+    self.buckets.launch(len(self.buckets.slices) - 1)
+    return token_nll, nlls
+
+  # ----------------------------------------------------------------- optimizer
+  def optimizer_step(self):
+    """clip_grad_norm_ + AdamW + lr schedule + EMA (diffusion.py:254-259,
+    449-471) and the bf16 refresh of the GEMM weights, one launch."""
+    self.buckets.wait_all()
+    lr = constant_warmup_lr(self.lr, self.step_count, self.num_warmup_steps)
+    self.step_count += 1
+    ops.grad_sumsq(self.G, self._sumsq_part, self._sumsq)
+    scale = 1.0 / self.world
+    self.last_grad_norm = self._sumsq  # device: sum of squares of the summed grads
+    n = self.step_count
+    omd = 1.0 - min(self.ema_decay, (1 + n) / (10 + n)) if self.E is not None else 0.0
+    ops.adamw_ema(self.P, self.G, self.M1, self.M2, self.E, self.W16, lr, self.betas[0],
+                  self.betas[1], self.eps, self.weight_decay, n, omd, sumsq=self._sumsq,
+                  max_norm=self.max_norm or 0.0, grad_scale=scale)
+    if getattr(self.model, 'ema', None):
+      self.model.ema.num_updates = n
+    self.bb.refresh()
+    return lr
+
+  def grad_norm(self):
+    return math.sqrt(float(self._sumsq.item())) / self.world
+
+  def training_step(self, batch):
+    """diffusion.py:390-397 + optimizer_step (254-259): returns the loss."""
+    loss, nlls = self.forward_backward(batch['input_ids'], batch.get('attention_mask'))
+    self.model.train_metrics.update(nlls, batch.get('attention_mask')
+                                    if batch.get('attention_mask') is not None
+                                    else torch.ones_like(nlls))
+    self.optimizer_step()
+    return loss

@@ -219,3 +219,123 @@ def test_adamw_ema_clip(ops):
     assert (sc.cpu() - st['s']).abs().max().item() < 2e-6
     assert _rel(mc, st['m']) < 1e-4 and _rel(vc, st['v']) < 1e-4
     assert torch.equal(w16.cpu(), pc.cpu().to(torch.bfloat16))
+
+
+# ----------------------------------------------------------- whole training step
+V_T, MASK_T = 300, 103     # mask id inside the vocabulary, like bert-base-uncased (LM1B)
+
+
+def _make_trainer(p_drop, time_conditioning=False, seed=5):
+  from mdlm_amd.config import load_config
+  from mdlm_amd.diffusion import Diffusion
+  from mdlm_amd.tokenizer import SyntheticTokenizer
+  from mdlm_amd.train import Trainer
+  cfg = load_config(['model=tiny', 'loader.eval_batch_size=4',
+                     f'time_conditioning={time_conditioning}'])
+  tok = SyntheticTokenizer(vocab_size=V_T, eos_token_id=7, mask_token_id=MASK_T)
+  model = Diffusion(cfg, tok).cuda()
+  assert model.mask_index == MASK_T and model.vocab_size == V_T
+  m = cfg.model
+  p = orc.synthetic_dit_params(m.hidden_size, m.n_heads, m.n_blocks, m.cond_dim, V_T, seed=seed)
+  sd = dict(p); sd['rotary_emb.inv_freq'] = model.backbone.rotary_emb.inv_freq
+  model.backbone.load_state_dict(sd)
+  tr = Trainer(model, lr=3e-3, num_warmup_steps=2, dropout=p_drop)
+  return model, cfg, p, tr
+
+
+def _batch(B, L, seed=0):
+  g = torch.Generator().manual_seed(seed)
+  x0 = torch.randint(0, V_T, (B, L), generator=g)
+  x0[x0 == MASK_T] = 0
+  attn = torch.ones(B, L); attn[1, -5:] = 0
+  t = orc.sample_t(B, torch.rand(B, generator=g))
+  u = torch.rand(B, L, generator=g)
+  return x0, attn, t, u
+
+
+@pytest.mark.parametrize('p_drop', [0.0, 0.1])
+def test_training_step_matches_oracle(ops, p_drop):
+  model, cfg, p, tr = _make_trainer(p_drop)
+  m = cfg.model
+  B, L, D = 4, m.length, m.hidden_size
+  x0, attn, t, u = _batch(B, L)
+  loss, nlls = tr.forward_backward(x0.cuda(), attn.cuda(), t=t.cuda(), u_xt=u.cuda())
+  keep = None
+  if p_drop > 0:
+    keep = []
+    for a in tr._ws['blocks']:
+      keep.append(tuple(
+        (ops.philox_uniform(B * L, D, model._rng_seed, off).cpu() >= p_drop).view(B, L, D)
+        for off in a['drop']))
+  ref_loss, ref_nlls, ref_g = orc.loss_and_grads(p, x0, attn, t, u, m.n_heads, m.n_blocks,
+                                                 MASK_T, keep, p_drop)
+  assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item())
+  assert _rel(nlls, ref_nlls) < 2e-2
+  g = tr.grads()
+  worst = max((_rel(g[k], ref_g[k]), k) for k in ref_g)
+  flat = torch.cat([g[k].reshape(-1).cpu() for k in ref_g]).double()
+  flat_ref = torch.cat([ref_g[k].reshape(-1) for k in ref_g]).double()
+  cos = (flat @ flat_ref) / (flat.norm() * flat_ref.norm())
+  assert cos.item() > 0.999, cos.item()
+  assert worst[0] < 6e-2, worst
+  # the optimizer consumes those gradients exactly as the oracle's AdamW does
+  st = orc.new_train_state({k: v.clone() for k, v in p.items()})
+  gcpu = {k: g[k].detach().cpu().clone() for k in ref_g}
+  total, coef = orc.clip_coef(gcpu, 1.0)
+  lr = tr.optimizer_step()
+  assert lr == orc.constant_warmup_lr(3e-3, 0, 2) == 0.0
+  assert abs(tr.grad_norm() - total.item()) < 1e-4 * total.item()
+  # second step with a non-zero learning rate
+  tr.forward_backward(x0.cuda(), attn.cuda(), t=t.cuda(), u_xt=u.cuda())
+  g2 = {k: v.detach().cpu().clone() for k, v in tr.grads().items()}
+  lr = tr.optimizer_step()
+  assert abs(lr - 1.5e-3) < 1e-12
+  for step, gg, lr_ in ((1, gcpu, 0.0), (2, g2, 1.5e-3)):
+    _, cf = orc.clip_coef(gg, 1.0)
+    st['step'] = step
+    for k in st['params']:
+      orc.adamw_step(st['params'][k], gg[k] * cf, st['m'][k], st['v'][k], step, lr_)
+      orc.ema_update(st['shadow'][k], st['params'][k], 0.9999, step)
+  sd = model.backbone.state_dict()
+  ema = tr.ema_state_dict()
+  for i, k in enumerate(tr.names):
+    assert (sd[k].cpu() - st['params'][k]).abs().max().item() < 2e-6, k
+    assert (ema['shadow_params'][i].cpu() - st['shadow'][k]).abs().max().item() < 2e-6, k
+  assert ema['num_updates'] == 2
+  # the eval path sees the new weights (bf16 copies refreshed)
+  lg = model.backbone(x0.cuda(), torch.zeros(B, device='cuda')).float().cpu()
+  ref_lg = orc.dit_forward(st['params'], x0, torch.zeros(B), m.n_heads, m.n_blocks)
+  assert _rel(lg, ref_lg) < 2e-2
+
+
+def test_training_reduces_loss_and_time_conditioning(ops):
+  model, cfg, p, tr = _make_trainer(0.1, time_conditioning=True)
+  B, L = 4, cfg.model.length
+  x0, attn, t, u = _batch(B, L, seed=3)
+  # per-sample conditioning: gradient parity with dropout off is covered above;
+  # here the time-conditioned path runs end to end and the loss goes down
+  tr.num_warmup_steps = 0
+  losses = []
+  for _ in range(12):
+    loss, _ = tr.forward_backward(x0.cuda(), attn.cuda(), t=t.cuda(), u_xt=u.cuda())
+    tr.optimizer_step()
+    losses.append(loss.item())
+  assert all(math.isfinite(v) for v in losses)
+  assert losses[-1] < 0.8 * losses[0], losses
+
+
+def test_time_conditioned_gradients(ops):
+  model, cfg, p, tr = _make_trainer(0.0, time_conditioning=True)
+  m = cfg.model
+  B, L = 4, m.length
+  x0, attn, t, u = _batch(B, L, seed=4)
+  tr.forward_backward(x0.cuda(), attn.cuda(), t=t.cuda(), u_xt=u.cuda())
+  sigma, dsigma = orc.loglinear_noise(t)
+  leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+  xt = orc.q_xt(x0, 1 - torch.exp(-sigma[:, None]), u, MASK_T)
+  logits = orc.dit_forward(leaves, xt, sigma, m.n_heads, m.n_blocks)
+  nlls, token_nll = orc.nelbo_from_logits(logits, xt, x0, t, attn, MASK_T)
+  grads = torch.autograd.grad(token_nll, list(leaves.values()))
+  g = tr.grads()
+  for k, gr in zip(leaves, grads):
+    assert _rel(g[k], gr) < 6e-2, k
