@@ -7,8 +7,14 @@
 
 Multi-GPU: `python -m torch.distributed.run --nproc-per-node N main.py mode=...`
 (one process per GPU; samples / eval sequences are sharded by rank, the only
-collective is the fp64 NELBO pair all-reduce).  `mode=train` is out of scope
-for this hot path.
+collective is the fp64 NELBO pair all-reduce).
+
+  python main.py mode=train data=lm1b model.length=128 loader.global_batch_size=512 \
+      trainer.max_steps=100        (scripts/train_lm1b_d3pm.sh recipe with MDLM defaults)
+
+`mode=train` runs mdlm_amd.train.Trainer: hand-written backward
+kernels, flat AdamW/EMA buffers and the DDP gradient all-reduce on RCCL, on
+synthetic LM1B/OWT-shaped batches (the datasets need the network).
 """
 import json
 import sys
@@ -118,6 +124,41 @@ def _ppl_eval(config, tokenizer):  # main.py:119-145 + diffusion.py:399-413
   return res
 
 
+def _train(config, tokenizer):  # main.py:148-183 + diffusion.py:390-397, 254-259
+  from mdlm_amd.diffusion import Diffusion
+  from mdlm_amd.train import Trainer
+  world, rank = mdist.world_size(), mdist.rank()
+  model = Diffusion(config, tokenizer=tokenizer).cuda()
+  if config.eval.checkpoint_path:
+    _load_backbone_weights(model, config.eval.checkpoint_path)
+  else:
+    _synthetic_weights(model, config.seed)   # same seed on every rank (DDP replicas)
+  model.seed_rng(mdist.rank_seed(config.seed, rank))
+  trainer = Trainer(model, max_norm=config.trainer.gradient_clip_val,
+                    num_warmup_steps=config.lr_scheduler.num_warmup_steps)
+  B, L = config.loader.batch_size, config.model.length
+  accum = int(config.trainer.accumulate_grad_batches)
+  g = torch.Generator(device='cuda').manual_seed(int(config.seed) + 1000 * rank)
+  torch.manual_seed(int(config.seed) + rank)   # _sample_t draws from the default generator
+  t0, tok = time.perf_counter(), 0
+  for step in range(int(config.trainer.max_steps)):
+    for micro in range(accum):
+      ids = torch.randint(0, tokenizer.vocab_size, (B, L), generator=g, device='cuda')
+      ids[ids == model.mask_index] = 0
+      ids[:, 0] = tokenizer.bos_token_id
+      ids[:, -1] = tokenizer.eos_token_id
+      batch = {'input_ids': ids, 'attention_mask': torch.ones(B, L, device='cuda')}
+      loss = trainer.training_step(batch, accumulate=micro > 0, step=micro == accum - 1)
+      tok += B * L
+    if rank == 0 and (step + 1) % int(config.trainer.log_every_n_steps) == 0:
+      torch.cuda.synchronize()
+      dt = time.perf_counter() - t0
+      print(json.dumps({'mode': 'train', 'step': step + 1, 'trainer/loss': float(loss),
+                        'lr': trainer.last_lr, 'tokens_per_sec': tok * world / dt,
+                        'world_size': world}), flush=True)
+  return trainer
+
+
 def main(argv=None):
   argv = sys.argv[1:] if argv is None else argv
   rank, local_rank, world = mdist.init()
@@ -131,8 +172,10 @@ def main(argv=None):
     generate_samples(config, tokenizer)
   elif config.mode == 'ppl_eval':
     _ppl_eval(config, tokenizer)
+  elif config.mode == 'train':
+    _train(config, tokenizer)
   else:
-    raise SystemExit(f'mode={config.mode}: only sample_eval and ppl_eval are on this hot path')
+    raise SystemExit(f'mode={config.mode}: expected sample_eval, ppl_eval or train')
   mdist.barrier()
 
 

@@ -41,6 +41,17 @@ MODELS = {
                dropout=0.1, tie_word_embeddings=False),
 }
 
+# configs/data/{openwebtext-split,lm1b}.yaml: the keys the hot path reads
+DATA = {
+  'openwebtext': dict(train='openwebtext', valid='openwebtext',
+                      tokenizer_name_or_path='gpt2', synthetic=True, vocab_size=50257),
+  'openwebtext-split': dict(train='openwebtext-train', valid='openwebtext-valid',
+                            tokenizer_name_or_path='gpt2', synthetic=True, vocab_size=50257),
+  # bert-base-uncased has its own [MASK] (id 103) -> V stays 30,522 (diffusion.py:85-90)
+  'lm1b': dict(train='lm1b', valid='lm1b', tokenizer_name_or_path='bert-base-uncased',
+               synthetic=True, vocab_size=30522),
+}
+
 DEFAULTS = dict(
   mode='sample_eval', diffusion='absorbing_state', backbone='dit',
   parameterization='subs', time_conditioning=False, T=0, subs_masking=False,
@@ -64,7 +75,10 @@ DEFAULTS = dict(
             gen_ppl_eval_model_name_or_path='gpt2-large',
             generate_samples=True, num_batches=4),
   optim=dict(weight_decay=0, lr=3e-4, beta1=0.9, beta2=0.999, eps=1e-8),
-  trainer=dict(accelerator='cuda', num_nodes=1, devices=1, precision='bf16'),
+  trainer=dict(accelerator='cuda', num_nodes=1, devices=1, precision='bf16',
+               accumulate_grad_batches=None, gradient_clip_val=1.0, max_steps=1_000_000,
+               log_every_n_steps=10),
+  lr_scheduler=dict(name='constant_warmup', num_warmup_steps=2500),
   noise=dict(type='loglinear', sigma_min=1e-4, sigma_max=20),
   data=dict(train='openwebtext', valid='openwebtext',
             tokenizer_name_or_path='gpt2', synthetic=True, vocab_size=50257),
@@ -102,6 +116,9 @@ def load_config(overrides=(), world_size=1):
     if key == 'model' and val in MODELS:
       cfg['model'] = _wrap(copy.deepcopy(MODELS[val]))
       continue
+    if key == 'data' and val in DATA:
+      cfg['data'] = _wrap(copy.deepcopy(DATA[val]))
+      continue
     _set(cfg, key, yaml.safe_load(val), create)
   cfg.trainer.devices = cfg.trainer.devices or world_size
   n = max(1, int(cfg.trainer.devices) * int(cfg.trainer.num_nodes))
@@ -110,4 +127,8 @@ def load_config(overrides=(), world_size=1):
     cfg.loader.batch_size = _div_up(cfg.loader.global_batch_size, n)
   if cfg.loader.eval_batch_size is None:
     cfg.loader.eval_batch_size = _div_up(cfg.loader.eval_global_batch_size, n)
+  # configs/config.yaml:68: accumulate = div_up(global, devices * batch * nodes)
+  if cfg.trainer.accumulate_grad_batches is None:
+    cfg.trainer.accumulate_grad_batches = _div_up(cfg.loader.global_batch_size,
+                                                  n * cfg.loader.batch_size)
   return cfg

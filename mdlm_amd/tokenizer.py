@@ -32,4 +32,11 @@ def get_tokenizer(config):
   if isinstance(path, str) and os.path.isdir(path):
     import transformers
     return transformers.AutoTokenizer.from_pretrained(path)
+  if isinstance(path, str) and 'bert' in path:
+    # bert-base-uncased contract (dataloader.py:488-522): [CLS]=101 as BOS,
+    # [SEP]=102 as EOS, [PAD]=0, an in-vocabulary [MASK]=103
+    tok = SyntheticTokenizer(vocab_size=int(config.data.get('vocab_size', 30522)),
+                             bos_token_id=101, eos_token_id=102, mask_token_id=103)
+    tok.pad_token_id = 0
+    return tok
   return SyntheticTokenizer(vocab_size=int(config.data.get('vocab_size', 50257)))

@@ -48,6 +48,8 @@ class GradBuckets:
   def __init__(self, flat, slices, group=None):
     self.flat, self.slices, self.group = flat, slices, group
     self.work = []
+    self.hold = False    # no_sync: a micro-batch that is not the last of its step
+    self.carry = None    # gradients of the earlier micro-batches of this step
     self.stream = torch.cuda.Stream() if flat.is_cuda else None
 
   @property
@@ -55,10 +57,12 @@ class GradBuckets:
     return dist.is_initialized() and dist.get_world_size(self.group) > 1
 
   def launch(self, i):
-    if not self.enabled:
-      return
     a, b = self.slices[i]
-    if b <= a:
+    if b <= a or self.hold:
+      return
+    if self.carry is not None:
+      self.flat[a:b] += self.carry[a:b]
+    if not self.enabled:
       return
     if self.stream is not None:
       self.stream.wait_stream(torch.cuda.current_stream())
@@ -137,6 +141,8 @@ class Trainer:
     slices.append((0, span('blocks.0.')[0]))
     self.buckets = GradBuckets(self.G, slices, group)
     self._ws = None
+    self.A, self.micro = None, 0   # accumulation carry (allocated on first use)
+    self.last_lr = None
     self._sumsq = torch.zeros(1, device=dev)
     self._sumsq_part = torch.empty(1024, device=dev)
     self.last_grad_norm = None
@@ -229,9 +235,21 @@ class Trainer:
     return da_out
 
   # ----------------------------------------------------------- forward/backward
-  def forward_backward(self, x0, attention_mask=None, t=None, u_xt=None):
+  def forward_backward(self, x0, attention_mask=None, t=None, u_xt=None,
+                       accumulate=False, last=True):
     """Loss of one micro-batch and its gradients into the flat buffer G
-    (overwritten).  Returns (token_nll device scalar, nlls (B, L))."""
+    (overwritten).  Returns (token_nll device scalar, nlls (B, L)).
+
+    Gradient accumulation (configs/config.yaml:68): micro-batches with
+    `last=False` keep their gradients local (DDP no_sync) in a carry buffer;
+    `accumulate=True` adds that carry to this micro-batch's gradients, bucket
+    by bucket, just before each bucket's all-reduce.  The 1/accum mean is
+    folded into the optimizer kernel's gradient scale."""
+    self.buckets.hold = not last
+    self.buckets.carry = self.A if accumulate else None
+    if not accumulate:
+      self.micro = 0
+    self.micro += 1
     model, bb = self.model, self.bb
     B, L = x0.shape
     D, H, V = bb.hidden, bb.n_heads, bb.vocab_size
@@ -367,6 +385,13 @@ class Trainer:
       self.buckets.launch(self.bucket_ids[i])
     ops.embed_grad(dx, xt.view(-1), self._g('vocab_embed.embedding'))
     self.buckets.launch(len(self.buckets.slices) - 1)
+    if not last:
+      if self.A is None:
+        self.A = torch.zeros_like(self.G)
+      if accumulate:
+        self.A += self.G
+      else:
+        self.A.copy_(self.G)
     return token_nll, nlls
 
   # ----------------------------------------------------------------- optimizer
@@ -377,7 +402,8 @@ class Trainer:
     lr = constant_warmup_lr(self.lr, self.step_count, self.num_warmup_steps)
     self.step_count += 1
     ops.grad_sumsq(self.G, self._sumsq_part, self._sumsq)
-    scale = 1.0 / self.world
+    scale = 1.0 / (self.world * max(1, self.micro))
+    self.last_lr = lr
     self.last_grad_norm = self._sumsq  # device: sum of squares of the summed grads
     n = self.step_count
     omd = 1.0 - min(self.ema_decay, (1 + n) / (10 + n)) if self.E is not None else 0.0
@@ -390,13 +416,17 @@ class Trainer:
     return lr
 
   def grad_norm(self):
-    return math.sqrt(float(self._sumsq.item())) / self.world
+    return math.sqrt(float(self._sumsq.item())) / (self.world * max(1, self.micro))
 
-  def training_step(self, batch):
-    """diffusion.py:390-397 + optimizer_step (254-259): returns the loss."""
-    loss, nlls = self.forward_backward(batch['input_ids'], batch.get('attention_mask'))
+  def training_step(self, batch, accumulate=False, step=True):
+    """diffusion.py:390-397 + optimizer_step (254-259): returns the loss.
+    `accumulate`: add to the gradients of the previous micro-batches;
+    `step=False`: not the last micro-batch of this optimizer step."""
+    loss, nlls = self.forward_backward(batch['input_ids'], batch.get('attention_mask'),
+                                       accumulate=accumulate, last=step)
     self.model.train_metrics.update(nlls, batch.get('attention_mask')
                                     if batch.get('attention_mask') is not None
                                     else torch.ones_like(nlls))
-    self.optimizer_step()
+    if step:
+      self.optimizer_step()
     return loss

@@ -339,3 +339,29 @@ def test_time_conditioned_gradients(ops):
   g = tr.grads()
   for k, gr in zip(leaves, grads):
     assert _rel(g[k], gr) < 6e-2, k
+
+
+def test_gradient_accumulation(ops):
+  """configs/config.yaml:68 accumulate_grad_batches: the carry of the held
+  micro-batches is added bucket by bucket, the mean is taken in the optimizer."""
+  model, cfg, p, tr = _make_trainer(0.0)
+  B, L = 4, cfg.model.length
+  xa, attn, ta, ua = _batch(B, L, seed=11)
+  xb, _, tb, ub = _batch(B, L, seed=12)
+  tr.forward_backward(xa.cuda(), attn.cuda(), t=ta.cuda(), u_xt=ua.cuda())
+  ga = {k: v.detach().clone() for k, v in tr.grads().items()}
+  tr.forward_backward(xb.cuda(), attn.cuda(), t=tb.cuda(), u_xt=ub.cuda())
+  gb = {k: v.detach().clone() for k, v in tr.grads().items()}
+  tr.forward_backward(xa.cuda(), attn.cuda(), t=ta.cuda(), u_xt=ua.cuda(), last=False)
+  tr.forward_backward(xb.cuda(), attn.cuda(), t=tb.cuda(), u_xt=ub.cuda(), accumulate=True)
+  g = tr.grads()
+  for k in ga:
+    ref = ga[k] + gb[k]
+    assert (g[k] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-9, k
+  assert tr.micro == 2
+  tr.optimizer_step()
+  total = torch.sqrt(sum(((ga[k] + gb[k]) / 2).double().pow(2).sum() for k in ga)).item()
+  assert abs(tr.grad_norm() - total) < 1e-4 * total
+  # a step without accumulation resets the micro-batch count
+  tr.forward_backward(xa.cuda(), attn.cuda(), t=ta.cuda(), u_xt=ua.cuda())
+  assert tr.micro == 1

@@ -225,12 +225,25 @@ mdist.all_reduce_sums(sums)
 tok = torch.arange(4).view(1, 4) + 10 * rank
 allt = mdist.gather_tokens(tok)
 mx = mdist.max_over_ranks(1.0 + rank, 'cpu')
+# DDP gradient buckets of the trainer (configs/strategy/ddp.yaml): contiguous
+# slices of one flat gradient buffer, summed across ranks as they are launched
+from mdlm_amd.train import GradBuckets
+torch.manual_seed(7)
+base = torch.randn(2, 1000)
+flat = base[rank].clone()
+slices = [(640, 1000), (128, 640), (64, 128), (64, 64), (0, 64)]
+gb = GradBuckets(flat, slices)
+assert gb.enabled
+for i in range(len(slices)):
+  gb.launch(i)
+gb.wait_all()
+ddp_ok = bool(torch.equal(flat, base[0] + base[1])) and gb.work == []
 mdist.barrier()
 if rank == 0:
   full = mdist.shard_indices(11, 0, 2) + mdist.shard_indices(11, 1, 2)
   ref = torch.stack([(nll[full] * mask[full]).sum(), mask[full].sum()])
   print(json.dumps({'ok': bool(torch.allclose(sums, ref)), 'gathered': allt.tolist(),
-                    'max': mx, 'seeds': [mdist.rank_seed(1, r) for r in range(world)]}))
+                    'max': mx, 'ddp_ok': ddp_ok, 'seeds': [mdist.rank_seed(1, r) for r in range(world)]}))
 '''
 
 
@@ -249,5 +262,5 @@ def test_gloo_world_size_2(tmp_path):
     assert p.returncode == 0, e[-2000:]
   import json
   res = json.loads(outs[0][0].strip().splitlines()[-1])
-  assert res['ok'] and res['max'] == 2.0 and res['seeds'] == [1, 2]
+  assert res['ok'] and res['ddp_ok'] and res['max'] == 2.0 and res['seeds'] == [1, 2]
   assert res['gathered'] == [[0, 1, 2, 3], [10, 11, 12, 13]]
