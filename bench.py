@@ -127,8 +127,62 @@ def cpu_baseline(cfg, T, budget_s=20.0):
   }
 
 
+def train_bench(args):
+  """BASELINE.json configs[4]: LM1B MDLM training step, DiT-small, L=128, global
+  batch 512 split over the ranks (strong scaling), bert-base-uncased-shaped
+  vocabulary (30,522, [MASK]=103 in-vocabulary), dropout 0.1, clip 1.0, AdamW,
+  EMA, DDP gradient all-reduce on RCCL overlapped with the backward.  A step =
+  forward + backward + all-reduce + optimizer/EMA over one global batch."""
+  from mdlm_amd.train import Trainer
+  rank, local_rank, world = mdist.init()
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  gb = args.global_batch
+  cfg = load_config(['model=small', 'data=lm1b', 'model.length=128',
+                     f'loader.global_batch_size={gb}', f'trainer.devices={world}'])
+  model = build_model(cfg, seed=1)   # same weights on every rank
+  model.seed_rng(mdist.rank_seed(cfg.seed, rank))
+  tr = Trainer(model, num_warmup_steps=cfg.lr_scheduler.num_warmup_steps)
+  B, L, V = cfg.loader.batch_size, cfg.model.length, model.vocab_size
+  g = torch.Generator(device='cuda').manual_seed(1 + rank)
+  ids = torch.randint(0, V, (B, L), generator=g, device='cuda')
+  ids[ids == model.mask_index] = 0
+  ids[:, 0] = 101; ids[:, -1] = 102
+  batch = {'input_ids': ids, 'attention_mask': torch.ones(B, L, device='cuda')}
+  torch.manual_seed(1 + rank)
+  for _ in range(max(1, args.warmup)):
+    loss = tr.training_step(batch)
+  torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
+  steps = args.steps if args.steps > 2 else 20
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    loss = tr.training_step(batch)
+  torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
+  el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+  n_par = sum(p.numel() for p in model.backbone.parameters())
+  # forward flops per token: blocks 2*(3+1+8)*D^2 + attention 4*L*D, vocab 2*D*V; x3 for fwd+bwd
+  D, nb = cfg.model.hidden_size, cfg.model.n_blocks
+  f_tok = nb * (24 * D * D + 4 * L * D) + 2 * D * V
+  out = {'metric': 'LM1B MDLM training step tokens/sec (DiT-small, L=128, global batch 512)',
+         'value': round(world * B * L * steps / el, 1), 'unit': 'tokens/s', 'n_gpus': world,
+         'steps': steps, 'warmup': max(1, args.warmup), 'ms_per_step': round(el / steps * 1e3, 2),
+         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16',
+         'data': 'synthetic',
+         'config': {'workload': f'LM1B MDLM training step, DiT-small ({n_par/1e6:.1f}M), L={L}, '
+                                f'global batch {world * B}, V={V}, dropout 0.1, clip 1.0, AdamW+EMA',
+                    'batch_per_gpu': B, 'parallelism': f'ddp x{world}',
+                    'grad_allreduce_mbytes': round(tr.n_flat * 4 / 1e6, 1)},
+         'loss': round(float(loss), 4),
+         'model_tflops': round(3 * f_tok * world * B * L * steps / el / 1e12, 1)}
+  if rank == 0:
+    print(json.dumps(out), flush=True)
+  mdist.barrier()
+
+
 def main():
   ap = argparse.ArgumentParser()
+  ap.add_argument('--workload', default='sample', choices=['sample', 'train'])
+  ap.add_argument('--global-batch', type=int, default=512)
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=2)
   ap.add_argument('--warmup', type=int, default=1)
@@ -140,6 +194,8 @@ def main():
   ap.add_argument('--no-policy-compare', action='store_true')
   ap.add_argument('--no-eval', action='store_true')
   args = ap.parse_args()
+  if args.workload == 'train':
+    return train_bench(args)
 
   rank, local_rank, world = mdist.init()
   if world != args.gpus:

@@ -268,6 +268,21 @@ int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
  * outputs are then undefined. */
 int mdlm_gemm_set_tile(int force_small);
 
+/* Weight gradient of an nn.Linear in the training step (autograd of
+ * dit.py:220-232, 256, 277, 306/320 under diffusion.py:390-397): the
+ * contraction runs over the token dimension K_total and the output is small,
+ * so K is cut into `splits` ranges that run as independent tiles:
+ *   partials[s][M][N] = A[:, s*Kc:(s+1)*Kc] @ W[:, s*Kc:(s+1)*Kc]^T   (fp32),
+ * Kc = K_total / splits, K_total % (splits*64) == 0, M % 128 == 0, N % 4 == 0;
+ * A (M, K_total) ld lda, W (N, K_total) ld ldw, both bf16.
+ * mdlm_splitk_reduce then writes out[i] = sum_s partials[s*split_stride + i]
+ * for i < n, added in split order (deterministic). */
+int mdlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw,
+                          float* partials, int64_t M, int N, int64_t K_total,
+                          int splits, void* stream);
+int mdlm_splitk_reduce(const float* partials, float* out, int64_t n, int splits,
+                       int64_t split_stride, void* stream);
+
 /* Bidirectional attention, dit.py:265-275 (flash_attn_varlen_qkvpacked_func,
  * equal lengths, no dropout, softmax scale 1/sqrt(64)): q,k (n_seq,H,L,64)
  * bf16, vt (n_seq,H,64,L) bf16 -> out (n_seq*L, H*64) bf16.  L % 128 == 0. */

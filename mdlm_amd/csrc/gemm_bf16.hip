@@ -35,7 +35,10 @@ constexpr int BK = 64;
 
 struct GemmArgs {
   const bf16_t* A; int64_t lda;
-  const bf16_t* W;
+  const bf16_t* W; int64_t ldw;
+  // split-K (fp32 EPI_STORE only): split s reduces K columns [s*K, (s+1)*K) of
+  // A and W into C + s*c_split_stride (partial sums, added up by a second kernel)
+  int splits; int64_t c_split_stride;
   const float* bias;
   void* C; int64_t ldc;
   int64_t M; int N; int K;
@@ -365,14 +368,21 @@ void gemm_bf16_kernel(GemmArgs g) {
   const int64_t m_lim = g.m_rows_dev ? (int64_t)*g.m_rows_dev : g.M;
   const int64_t vm_live = (m_lim + TBM - 1) / TBM;
   const int vm = vm_live < g.tiles_m ? (int)vm_live : g.tiles_m;  // valid M tiles
-  const int total = vm * g.tiles_n;
+  constexpr bool SPLITK = EPI == MDLM_EPI_STORE && !BF16_OUT;
+  const int per_split = vm * g.tiles_n;
+  const int total = SPLITK ? per_split * g.splits : per_split;
   const int per_xcd = (total + 7) >> 3;
   const int s_begin = xcd * per_xcd;
   const int s_end = total < s_begin + per_xcd ? total : s_begin + per_xcd;
   // tile at index j of this XCD's range (-1: past its end)
-  auto next_tile = [&](int j, int& tm, int& tn) -> int {
-    const int s = s_begin + j;
+  auto next_tile = [&](int j, int& tm, int& tn, int& sp) -> int {
+    int s = s_begin + j;
     if (s >= s_end) return -1;
+    sp = 0;
+    if constexpr (SPLITK) {   // split outermost: neighbours share the K range
+      sp = s / per_split;
+      s -= sp * per_split;
+    }
     const int gl = s / per_group;
     const int rem = s - gl * per_group;
     const int left = vm - gl * GROUP_M;
@@ -389,17 +399,18 @@ void gemm_bf16_kernel(GemmArgs g) {
   const int skc = ((lane & 7) ^ srow) * 8;  // element offset inside the 64-wide K slab
   const bf16_t* a_src[A_CH];
   const bf16_t* b_src[B_CH];
-  auto set_src = [&](int tm, int tn) {
+  auto set_src = [&](int tm, int tn, int sp) {
     const int64_t m0 = (int64_t)tm * TBM;
     const int n0 = tn * TBN;
+    const int64_t kofs = (SPLITK ? (int64_t)sp * g.K : 0) + skc;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
-      a_src[i] = g.A + (m0 + (i * NW + wid) * 8 + srow) * g.lda + skc;
+      a_src[i] = g.A + (m0 + (i * NW + wid) * 8 + srow) * g.lda + kofs;
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       int brow = n0 + (i * NW + wid) * 8 + srow;
       brow = brow < g.N ? brow : g.N - 1;  // clamp the N edge (stores are masked)
-      b_src[i] = g.W + (int64_t)brow * g.K + skc;
+      b_src[i] = g.W + (int64_t)brow * g.ldw + kofs;
     }
   };
   auto stage = [&](int buf, int k0) {
@@ -423,17 +434,17 @@ void gemm_bf16_kernel(GemmArgs g) {
   const int b_base = A_BYTES + wc * 64 * 128;
   const int KT = g.K / BK;
 
-  int tm, tn;
-  int j = next_tile(bid >> 3, tm, tn);
+  int tm, tn, sp;
+  int j = next_tile(bid >> 3, tm, tn, sp);
   if (j < 0) return;
-  set_src(tm, tn);
+  set_src(tm, tn, sp);
   stage(0, 0);
   int buf = 0;          // stage holding the slab the next K step reads
   __syncthreads();      // hipcc drains the LDS-DMA (vmcnt(0)) before the barrier
 
   while (true) {
-    int tm_next, tn_next;
-    const int j_next = next_tile(j + slots, tm_next, tn_next);
+    int tm_next, tn_next, sp_next;
+    const int j_next = next_tile(j + slots, tm_next, tn_next, sp_next);
     const int64_t m0 = (int64_t)tm * TBM;
     const int n0 = tn * TBN;
     const int gcol0 = n0 + wc * 64;
@@ -487,7 +498,7 @@ void gemm_bf16_kernel(GemmArgs g) {
         if (kt + 1 < KT) {
           stage(buf ^ 1, (kt + 1) * BK);
         } else if (j_next >= 0) {
-          set_src(tm_next, tn_next);   // first slab of the next tile
+          set_src(tm_next, tn_next, sp_next);   // first slab of the next tile
           stage(buf ^ 1, 0);
         }
         const char* At = smem + buf * STAGE + a_base;
@@ -550,6 +561,15 @@ void gemm_bf16_kernel(GemmArgs g) {
       if constexpr (BF16_OUT) {
         epilogue_sub<EPI, TC, MT, 0, 4>(acc, ep, growW, gcol0, ec, g, lane_e);
         if constexpr (MT == 8) epilogue_sub<EPI, TC, MT, 4, 4>(acc, ep, growW + 64, gcol0, ec, g, lane_e);
+      } else if constexpr (SPLITK) {
+        GemmArgs gs = g;   // this split's partial-sum plane
+        gs.C = reinterpret_cast<float*>(g.C) + (int64_t)sp * g.c_split_stride;
+        epilogue_sub<EPI, TC, MT, 0, 2>(acc, ep, growW, gcol0, ec, gs, lane_e);
+        epilogue_sub<EPI, TC, MT, 2, 2>(acc, ep, growW + 32, gcol0, ec, gs, lane_e);
+        if constexpr (MT == 8) {
+          epilogue_sub<EPI, TC, MT, 4, 2>(acc, ep, growW + 64, gcol0, ec, gs, lane_e);
+          epilogue_sub<EPI, TC, MT, 6, 2>(acc, ep, growW + 96, gcol0, ec, gs, lane_e);
+        }
       } else {
         epilogue_sub<EPI, TC, MT, 0, 2>(acc, ep, growW, gcol0, ec, g, lane_e);
         epilogue_sub<EPI, TC, MT, 2, 2>(acc, ep, growW + 32, gcol0, ec, g, lane_e);
@@ -562,7 +582,7 @@ void gemm_bf16_kernel(GemmArgs g) {
       reinterpret_cast<float*>(g.C)[0] = 1.f;
     }
     if (j_next < 0) break;
-    j = j_next; tm = tm_next; tn = tn_next;
+    j = j_next; tm = tm_next; tn = tn_next; sp = sp_next;
     // every wave must be done with its epilogue region before the next K
     // step's DMA overwrites that stage
     __syncthreads();
@@ -583,7 +603,7 @@ static int launch_cfg(GemmArgs g, hipStream_t s) {
   }
   g.tiles_m = (int)(g.M / TBM);
   g.tiles_n = (g.N + TBN - 1) / TBN;
-  int64_t grid = (((int64_t)g.tiles_m * g.tiles_n + 7) / 8) * 8;
+  int64_t grid = (((int64_t)g.tiles_m * g.tiles_n * (g.splits > 1 ? g.splits : 1) + 7) / 8) * 8;
   if (grid >= (1ll << 31)) { set_error("gemm: grid too large"); return -1; }
   // persistent launch: one workgroup per CU for the 128 KiB-LDS tile, two for
   // the 64 KiB one
@@ -640,6 +660,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
   g.mod_ld = mod_ld; g.out_sample_map = out_sample_map; g.out_row_map = out_row_map;
   g.rot_cos = rot_cos; g.rot_sin = rot_sin; g.n_heads = n_heads; g.m_rows_dev = m_rows_dev;
   g.tiles_m = 0; g.tiles_n = 0; g.dbg = g_dbg;
+  g.ldw = K; g.splits = 1; g.c_split_stride = 0;
   hipStream_t s = (hipStream_t)stream;
   // 16-byte row stores: 8 bf16 or 4 fp32 per lane
   const int64_t per16 = dtype_c == MDLM_F32 ? 4 : 8;
@@ -673,4 +694,62 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
       MDLM_CHECK_ARG(false, "gemm_bf16: unknown epilogue %d", epilogue);
   }
   return -1;
+}
+
+
+// ---- split-K: weight-gradient GEMMs of the training step --------------------
+// dW[N_out, K_in] = dY^T X reduces over the TOKEN dimension (65,536 at the LM1B
+// batch) into a small output (768x768 = 9 tiles): without a split only a few
+// of the 256 CUs would work.  Split s writes the fp32 partial sum over its
+// token range into partials[s]; mdlm_splitk_reduce adds them in index order.
+namespace mdlm {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(
+    const float4* __restrict__ part, float4* __restrict__ out, int64_t n4, int splits,
+    int64_t stride4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = part[i];
+  for (int s = 1; s < splits; ++s) {
+    const float4 b = part[i + s * stride4];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  out[i] = a;
+}
+}  // namespace mdlm
+
+extern "C" int mdlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw,
+                                     float* partials, int64_t M, int N, int64_t K_total,
+                                     int splits, void* stream) {
+  if (M == 0) return 0;
+  MDLM_CHECK_ARG(A && W && partials, "gemm_bf16_splitk: null pointer");
+  MDLM_CHECK_ARG(M > 0 && N > 0 && K_total > 0 && splits >= 1 && splits <= 1024, "gemm_bf16_splitk: bad shape");
+  MDLM_CHECK_ARG(M % 128 == 0, "gemm_bf16_splitk: M=%lld must be a multiple of 128", (long long)M);
+  MDLM_CHECK_ARG(N % 4 == 0, "gemm_bf16_splitk: N must be a multiple of 4");
+  MDLM_CHECK_ARG(K_total % ((int64_t)splits * BK) == 0 && K_total / splits < (1ll << 31),
+                 "gemm_bf16_splitk: K=%lld must be a multiple of splits*%d", (long long)K_total, BK);
+  MDLM_CHECK_ARG(lda >= K_total && ldw >= K_total && lda % 8 == 0 && ldw % 8 == 0 &&
+                 ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)partials & 15) == 0,
+                 "gemm_bf16_splitk: operands must be 16-byte aligned with leading dimensions %% 8 == 0");
+  GemmArgs g;
+  g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = nullptr;
+  g.C = partials; g.ldc = N; g.M = M; g.N = N; g.K = (int)(K_total / splits);
+  g.gate = nullptr; g.residual = nullptr; g.rows_per_mod = 1; g.n_mod = 1; g.mod_ld = 0;
+  g.out_sample_map = nullptr; g.out_row_map = nullptr; g.rot_cos = nullptr; g.rot_sin = nullptr;
+  g.n_heads = 0; g.m_rows_dev = nullptr; g.tiles_m = 0; g.tiles_n = 0; g.dbg = 0;
+  g.splits = splits; g.c_split_stride = M * (int64_t)N; g.vec_ok = 1;
+  return launch_gemm<MDLM_EPI_STORE, float>(g, (hipStream_t)stream);
+}
+
+extern "C" int mdlm_splitk_reduce(const float* partials, float* out, int64_t n, int splits,
+                                  int64_t split_stride, void* stream) {
+  if (n == 0) return 0;
+  MDLM_CHECK_ARG(partials && out && n > 0 && splits >= 1, "splitk_reduce: bad args");
+  MDLM_CHECK_ARG(n % 4 == 0 && split_stride % 4 == 0 && ((uintptr_t)partials & 15) == 0 && ((uintptr_t)out & 15) == 0,
+                 "splitk_reduce: n, split_stride multiples of 4 and 16-byte aligned buffers");
+  const int64_t n4 = n / 4;
+  MDLM_CHECK_ARG((n4 + 255) / 256 < (1ll << 31), "splitk_reduce: too large");
+  splitk_reduce_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+    (const float4*)partials, (float4*)out, n4, splits, split_stride / 4);
+  MDLM_LAUNCH_CHECK();
+  return 0;
 }

@@ -125,16 +125,29 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(
   }
 }
 
-// out[o][c] = sum_{i < per_out} partial[o * per_out + i][c]   (fixed order)
-__global__ void colsum_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                     int64_t C, int per_out) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out[o][c] = sum_{i < per_out} partial[o * per_out + i][c]   (fixed order:
+// 16 interleaved row groups summed serially, then added up in group order)
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ partial,
+                                                             float* __restrict__ out,
+                                                             int64_t C, int per_out) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + tx;
   const int64_t o = blockIdx.y;
-  const float* p = partial + o * per_out * C + c;
   float s = 0.f;
-  for (int i = 0; i < per_out; ++i) s += p[(int64_t)i * C];
-  out[o * C + c] = s;
+  if (c < C) {
+    const float* p = partial + o * per_out * C + c;
+#pragma unroll 8
+    for (int i = ty; i < per_out; i += 16) s += p[(int64_t)i * C];
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    float t = red[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][tx];
+    out[o * C + c] = t;
+  }
 }
 
 // column sums of a bf16 matrix, stage 1: 128 rows per workgroup row-block
@@ -461,7 +474,7 @@ extern "C" int mdlm_colsum_reduce(const float* partial, float* out, int64_t C, i
                                   int n_out, void* stream) {
   if (C == 0 || n_out == 0) return 0;
   MDLM_CHECK_ARG(partial && out && C > 0 && per_out > 0 && n_out > 0 && n_out < 65536, "colsum_reduce: bad args");
-  colsum_reduce_kernel<<<dim3((unsigned)((C + 255) / 256), (unsigned)n_out), 256, 0, ST(stream)>>>(partial, out, C, per_out);
+  colsum_reduce_kernel<<<dim3((unsigned)((C + 63) / 64), (unsigned)n_out), 1024, 0, ST(stream)>>>(partial, out, C, per_out);
   MDLM_LAUNCH_CHECK();
   return 0;
 }

@@ -351,6 +351,38 @@ def gemm_bf16(A, W, C, epilogue=_lib.EPI_STORE, bias=None, gate=None,
   return C
 
 
+def splitk_plan(M, N, K_total, target_tiles=512, min_k=512):
+  """Number of K ranges for a weight-gradient GEMM (M, N: output; K_total:
+  tokens): the smallest power of two that gives the 256 CUs >= target_tiles
+  tiles while each range keeps >= min_k of K."""
+  t = 256 if M % 256 == 0 and N >= 256 else 128
+  tiles = (M // t) * ((N + t - 1) // t)
+  s = 1
+  while (tiles * s < target_tiles and K_total % (2 * s * 64) == 0
+         and K_total // (2 * s) >= min_k):
+    s *= 2
+  return s
+
+
+def gemm_bf16_splitk(A, W, out, partials, splits=None):
+  """out (M, N) fp32 = A (M, K) @ W (N, K)^T with K cut into `splits` ranges
+  (mdlm_gemm_bf16_splitk + mdlm_splitk_reduce); `partials` is an fp32
+  workspace of >= splits*M*N elements.  `out` may hold fewer than M rows (the
+  leading rows are written)."""
+  M, K = A.shape
+  N = W.shape[0]
+  assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and W.shape[1] == K
+  assert A.stride(1) == 1 and W.stride(1) == 1 and out.is_contiguous()
+  if splits is None:
+    splits = splitk_plan(M, N, K)
+  assert partials.numel() >= splits * M * N and partials.dtype == torch.float32
+  call('mdlm_gemm_bf16_splitk', A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0),
+       partials.data_ptr(), int(M), int(N), int(K), int(splits), _stream())
+  call('mdlm_splitk_reduce', partials.data_ptr(), out.data_ptr(), out.numel(),
+       int(splits), int(M * N), _stream())
+  return out
+
+
 def attn_fwd(q, k, vt, out, n_seq, H, L, n_seq_dev=None):
   call('mdlm_attn_fwd', q.data_ptr(), k.data_ptr(), vt.data_ptr(),
        out.data_ptr(), int(n_seq), int(H), int(L), _p(n_seq_dev), _stream())

@@ -166,7 +166,7 @@ class Trainer:
       return self._ws
     bb, dev = self.bb, self.dev
     D, H, V = bb.hidden, bb.n_heads, bb.vocab_size
-    M, Vp = B * L, ops.padded_vocab(V)
+    M, Vp = B * L, (V + 255) // 256 * 256   # 256-row tiles for the dW_vocab GEMM
     bf = torch.bfloat16
     e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)
     blocks = []
@@ -178,7 +178,11 @@ class Trainer:
     inv_freq = bb.rotary_emb.inv_freq.float()
     fr = torch.einsum('i,j->ij', torch.arange(L, device=dev).float(), inv_freq)
     nblk = M // 32
+    # split-K partial sums of the weight-gradient GEMMs (largest plan)
+    n_part = max(ops.splitk_plan(n, k, M) * n * k
+                 for n, k in ((3 * D, D), (D, D), (4 * D, D), (D, 4 * D), (Vp, D)))
     self._ws = dict(
+      skp=e(n_part, dt=torch.float32),
       key=key, blocks=blocks, x_last=e(M, D, dt=torch.float32), hf=e(M, D),
       logits=torch.zeros(M, Vp, dtype=bf, device=dev), dlogits=e(M, Vp),
       cos=fr.cos().to(bf).float().contiguous(), sin=fr.sin().to(bf).float().contiguous(),
@@ -187,7 +191,6 @@ class Trainer:
       delta=e(B * H * L, dt=torch.float32),
       tA=e(max(Vp, 4 * D) * M), tB=e(4 * D * M), wT=e(max(Vp * D, 4 * D * D)),
       wvT=torch.zeros(D, Vp, dtype=bf, device=dev),
-      dwv=e(Vp, D, dt=torch.float32),
       part3=e(nblk, 3, D, dt=torch.float32), part1=e(nblk, D, dt=torch.float32),
       partc=e((M + 127) // 128, max(Vp, 4 * D), dt=torch.float32))
     return self._ws
@@ -227,7 +230,7 @@ class Trainer:
     """y = a W^T (+ b): G[W] = dy^T a, G[b] = colsum(dy), da = dy W."""
     dyT = self._transpose(dy, ws['tA'])
     aT = self._transpose(a, ws['tB'])
-    ops.gemm_bf16(dyT, aT, self._g(wname), EPI_STORE)
+    ops.gemm_bf16_splitk(dyT, aT, self._g(wname), ws['skp'])
     if bname is not None:
       ops.colsum_bf16(dy, partial=ws['partc'], out=self._g(bname))
     if da_out is not None:
@@ -320,12 +323,11 @@ class Trainer:
     dl = ws['dlogits'][:, :V]
     ops.subs_nll_bwd(logits, xt.view(-1), x0.reshape(-1).contiguous(), row_w, dl, V,
                      model.mask_index)
-    # output layer: logits = hf Wv^T + bv (rows of dWv beyond V land in a scratch)
+    # output layer: logits = hf Wv^T + bv (rows of dWv beyond V stay in the partials)
     ops.colsum_bf16(dl, partial=ws['partc'], out=self._g('output_layer.linear.bias'))
     dlT = self._transpose(ws['dlogits'], ws['tA'])
     hfT = self._transpose(ws['hf'], ws['tB'])
-    ops.gemm_bf16(dlT, hfT, ws['dwv'], EPI_STORE)
-    self._g('output_layer.linear.weight').copy_(ws['dwv'][:V])
+    ops.gemm_bf16_splitk(dlT, hfT, self._g('output_layer.linear.weight'), ws['skp'])
     ops.transpose_bf16(self._w16('output_layer.linear.weight'), out=ws['wvT'][:, :V],
                        ld_out=ws['wvT'].stride(0))
     ops.gemm_bf16(ws['dlogits'], ws['wvT'], ws['d_md'], EPI_STORE)

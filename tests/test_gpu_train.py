@@ -365,3 +365,26 @@ def test_gradient_accumulation(ops):
   # a step without accumulation resets the micro-batch count
   tr.forward_backward(xa.cuda(), attn.cuda(), t=ta.cuda(), u_xt=ua.cuda())
   assert tr.micro == 1
+
+
+@pytest.mark.parametrize('M,N,K,splits', [(256, 768, 8192, 8), (384, 128, 4096, 4),
+                                          (768, 768, 2048, None), (512, 300, 1024, 1)])
+def test_gemm_splitk(ops, M, N, K, splits):
+  """Weight-gradient GEMM: K (tokens) cut into ranges, partial sums added in
+  split order; operands may be column slices of wider buffers (lda, ldw > K)."""
+  g = torch.Generator().manual_seed(M + N)
+  A = (torch.randn(M, K + 64, generator=g) * 0.5).to(torch.bfloat16)
+  W = (torch.randn(N, K + 128, generator=g) * 0.5).to(torch.bfloat16)
+  ref = A[:, :K].double() @ W[:, :K].double().T
+  s = ops.splitk_plan(M, N, K) if splits is None else splits
+  part = torch.empty(s * M * N, dtype=torch.float32, device='cuda')
+  out = torch.empty(M, N, dtype=torch.float32, device='cuda')
+  ops.gemm_bf16_splitk(A.cuda()[:, :K], W.cuda()[:, :K], out, part, splits=splits)
+  err = (out.cpu().double() - ref).abs().max().item()
+  assert err < 2e-4 * K ** 0.5, err
+  # run-to-run determinism (fixed summation order, no atomics)
+  out2 = torch.empty_like(out)
+  ops.gemm_bf16_splitk(A.cuda()[:, :K], W.cuda()[:, :K], out2, part, splits=splits)
+  assert torch.equal(out, out2)
+  if splits is None:
+    assert s == 4   # 9 tiles of 256x256; each range keeps >= 512 tokens: 2048 / 512 = 4
