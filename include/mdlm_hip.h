@@ -386,9 +386,14 @@ int mdlm_transpose_bf16(const void* in, int64_t ld_in, int64_t batch_stride_in,
                         void* out, int64_t ld_out, int64_t batch_stride_out,
                         int R, int C, int batch, void* stream);
 
-/* dtable[idx[r]] += dx[r] (fp32 atomics): backward of dit.py:298-299. */
+/* dtable[idx[r]] += dx[r]: backward of dit.py:298-299.  fp32 atomics, except
+ * for rows whose index is hot_index (>= 0: the mask token, which about half of
+ * a q_xt batch holds): those are summed in a fixed order through hot_partial
+ * (ceil(rows/128) x D floats) and WRITTEN to dtable[hot_index].  hot_index < 0:
+ * atomics only, hot_partial may be NULL. */
 int mdlm_embed_grad(const float* dx, const int64_t* idx, float* dtable,
-                    int64_t rows, int D, int vocab, void* stream);
+                    int64_t rows, int D, int vocab, int hot_index,
+                    float* hot_partial, void* stream);
 
 /* d(loss)/d(logits) of diffusion.py:261-277 + 884-916 for loss = sum_r
  * row_weight[r] * nll[r]: w*(softmax - onehot(x0)) on masked rows, 0 in the

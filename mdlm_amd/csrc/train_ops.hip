@@ -286,6 +286,51 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(
   }
 }
 
+// Fast path (R, C, leading dimensions multiples of 8, 16-byte aligned): 16-byte
+// loads of 8 columns, scattered into a TRANSPOSED LDS tile [64 c][64 r] whose
+// 16-byte chunk index is XOR-swizzled with (c >> 3) (the eight chunks a wave
+// writes per store instruction then fall into eight different bank groups),
+// read back as whole 16-byte chunks: eight lanes store 128 contiguous bytes
+// of one output row.
+__global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(
+    const bf16_t* __restrict__ in, int64_t ld_in, int64_t bs_in, bf16_t* __restrict__ out,
+    int64_t ld_out, int64_t bs_out, int R, int C) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 64];
+  const bf16_t* ib = in + (int64_t)blockIdx.z * bs_in;
+  bf16_t* ob = out + (int64_t)blockIdx.z * bs_out;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k = lane & 7;
+  uint4 v[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = r0 + w * 16 + it * 8 + (lane >> 3), c = c0 + k * 8;
+    v[it] = (r < R && c < C) ? *reinterpret_cast<const uint4*>(ib + (int64_t)r * ld_in + c)
+                             : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int rl = w * 16 + it * 8 + (lane >> 3);
+    const unsigned u[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int cl = k * 8 + j;
+      const bf16_t e = (bf16_t)(j & 1 ? u[j >> 1] >> 16 : u[j >> 1] & 0xffffu);
+      tile[cl * 64 + (((rl >> 3) ^ k) << 3) + (rl & 7)] = e;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int cl = w * 16 + it * 8 + (lane >> 3), rc = lane & 7;
+    const int c = c0 + cl, r = r0 + rc * 8;
+    if (c < C && r < R) {
+      const uint4 o = *reinterpret_cast<const uint4*>(tile + cl * 64 + ((rc ^ ((cl >> 3) & 7)) << 3));
+      *reinterpret_cast<uint4*>(ob + (int64_t)c * ld_out + r) = o;
+    }
+  }
+}
+
 // ----------------------------------------- d(qkv) from dq, dk, dv (head-major)
 // Inverse of the QKV epilogue: un-rotate dq / dk (dit.py:112-115 transposed:
 // dx1 = do1*c + do2*s, dx2 = -do1*s + do2*c) and lay the three gradients out
@@ -333,17 +378,36 @@ __global__ __launch_bounds__(256) void qkv_grad_pack_kernel(
 }
 
 // ---------------------------------------------------------- embedding gradient
+// dtable[idx[r]] += dx[r].  About half of the rows of a training batch hold
+// the mask token (q_xt): its table row would take ~rows/2 atomic adds per
+// element.  Rows whose index is `hot` are therefore summed per 128-row block
+// into hot_partial[block][D] (fixed order; mdlm_colsum_reduce then writes the
+// hot row), every other row goes through fp32 atomics.
+constexpr int EG_ROWS = 128;
 __global__ __launch_bounds__(256) void embed_grad_kernel(const float* __restrict__ dx, const int64_t* __restrict__ idx,
-                                                         float* __restrict__ dtable, int64_t rows, int D) {
+                                                         float* __restrict__ dtable, int64_t rows, int D,
+                                                         int hot, float* __restrict__ hot_partial) {
+  __shared__ int64_t sidx[EG_ROWS];
   const int nv = D / 4;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows * nv) return;
-  const int64_t r = i / nv;
-  const int c = (int)(i - r * nv);
-  const float4 v = reinterpret_cast<const float4*>(dx)[i];
-  float* d = dtable + idx[r] * D + c * 4;
-  unsafeAtomicAdd(d + 0, v.x); unsafeAtomicAdd(d + 1, v.y);
-  unsafeAtomicAdd(d + 2, v.z); unsafeAtomicAdd(d + 3, v.w);
+  const int64_t r0 = (int64_t)blockIdx.x * EG_ROWS;
+  const int nr = (int)(rows - r0 < EG_ROWS ? rows - r0 : EG_ROWS);
+  if (threadIdx.x < nr) sidx[threadIdx.x] = idx[r0 + threadIdx.x];
+  __syncthreads();
+  for (int c = threadIdx.x; c < nv; c += 256) {
+    float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < nr; ++i) {
+      const float4 v = reinterpret_cast<const float4*>(dx + (r0 + i) * D)[c];
+      const int64_t t = sidx[i];
+      if (t == hot) {
+        h.x += v.x; h.y += v.y; h.z += v.z; h.w += v.w;
+      } else {
+        float* d = dtable + t * D + c * 4;
+        unsafeAtomicAdd(d + 0, v.x); unsafeAtomicAdd(d + 1, v.y);
+        unsafeAtomicAdd(d + 2, v.z); unsafeAtomicAdd(d + 3, v.w);
+      }
+    }
+    if (hot_partial) reinterpret_cast<float4*>(hot_partial + (int64_t)blockIdx.x * D)[c] = h;
+  }
 }
 
 // ---------------------------------------------------------------- SUBS-NLL bwd
@@ -393,6 +457,82 @@ __global__ __launch_bounds__(256) void subs_nll_bwd_kernel(
         if (c == tgt) g -= w;
       }
       f[k] = g;
+    }
+    *reinterpret_cast<uint4*>(o + c0) = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
+                                                   pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+  }
+}
+
+// bf16 rows with 16-byte aligned, 8-element padded leading dimensions: one
+// online (max, sum) pass over 16-byte loads, then the row again (an L2 hit: the
+// same workgroup has just read its 60-100 KB) to form the gradient.
+__global__ __launch_bounds__(256) void subs_nll_bwd_vec_kernel(
+    const bf16_t* __restrict__ logits, int64_t ld, const int64_t* __restrict__ xt,
+    const int64_t* __restrict__ x0, const float* __restrict__ row_w, bf16_t* __restrict__ dl,
+    int64_t ldo, int V, int mask) {
+  __shared__ float red[8];
+  const int64_t r = blockIdx.x;
+  const int tid = threadIdx.x;
+  bf16_t* o = dl + r * ldo;
+  const float w = row_w[r];
+  if (xt[r] != mask || w == 0.f) {
+    for (int64_t c = (int64_t)tid * 8; c < ldo; c += 256 * 8)
+      *reinterpret_cast<uint4*>(o + c) = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  const bf16_t* lr = logits + r * ld;
+  const int V8 = (V + 7) & ~7;
+  auto unpack = [&](int c0, float (&f)[8]) {
+    const uint4 q = *reinterpret_cast<const uint4*>(lr + c0);
+    const unsigned u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[2 * k] = __uint_as_float(u[k] << 16);
+      f[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (c0 + k >= V || c0 + k == mask) f[k] = -INFINITY;
+  };
+  constexpr float LOG2E = 1.4426950408889634f;
+  float mx = -INFINITY, sm = 0.f;
+  for (int c0 = tid * 8; c0 < V8; c0 += 256 * 8) {
+    float f[8];
+    unpack(c0, f);
+    float m8 = f[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) m8 = fmaxf(m8, f[k]);
+    if (m8 > mx) { sm *= __builtin_amdgcn_exp2f((mx - m8) * LOG2E); mx = m8; }
+    if (mx > -INFINITY) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sm += __builtin_amdgcn_exp2f((f[k] - mx) * LOG2E);
+    }
+  }
+  const float wm = wave_max(mx);
+  if (mx > -INFINITY) sm *= __builtin_amdgcn_exp2f((mx - wm) * LOG2E);
+  sm = wave_sum(sm);
+  if ((tid & 63) == 0) { red[tid >> 6] = wm; red[4 + (tid >> 6)] = sm; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (red[k] > -INFINITY) s += red[4 + k] * __builtin_amdgcn_exp2f((red[k] - mx) * LOG2E);
+  const float ws = w / s;
+  const int tgt = (int)x0[r];
+  for (int64_t c0 = (int64_t)tid * 8; c0 < ldo; c0 += 256 * 8) {
+    float f[8];
+    if (c0 < V8) {
+      unpack((int)c0, f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float g = ws * __builtin_amdgcn_exp2f((f[k] - mx) * LOG2E);   // exp2(-inf) = 0
+        if ((int)c0 + k == tgt) g -= w;
+        f[k] = g;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = 0.f;
     }
     *reinterpret_cast<uint4*>(o + c0) = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
                                                    pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
@@ -554,8 +694,16 @@ extern "C" int mdlm_transpose_bf16(const void* in, int64_t ld_in, int64_t batch_
   if (R == 0 || C == 0 || batch == 0) return 0;
   MDLM_CHECK_ARG(in && out && R > 0 && C > 0 && batch > 0 && ld_in >= C && ld_out >= R, "transpose_bf16: bad args");
   MDLM_CHECK_ARG((R + 63) / 64 < 65536 && batch < 65536, "transpose_bf16: too large");
-  transpose_bf16_kernel<<<dim3((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64), (unsigned)batch), 256, 0, ST(stream)>>>(
-    (const bf16_t*)in, ld_in, batch_stride_in, (bf16_t*)out, ld_out, batch_stride_out, R, C);
+  const dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64), (unsigned)batch);
+  const bool vec = R % 8 == 0 && C % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 &&
+                   batch_stride_in % 8 == 0 && batch_stride_out % 8 == 0 &&
+                   (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+  if (vec)
+    transpose_bf16_vec_kernel<<<grid, 256, 0, ST(stream)>>>(
+      (const bf16_t*)in, ld_in, batch_stride_in, (bf16_t*)out, ld_out, batch_stride_out, R, C);
+  else
+    transpose_bf16_kernel<<<grid, 256, 0, ST(stream)>>>(
+      (const bf16_t*)in, ld_in, batch_stride_in, (bf16_t*)out, ld_out, batch_stride_out, R, C);
   MDLM_LAUNCH_CHECK();
   return 0;
 }
@@ -575,12 +723,23 @@ extern "C" int mdlm_qkv_grad_pack(const void* dq, const void* dk, const void* dv
 }
 
 extern "C" int mdlm_embed_grad(const float* dx, const int64_t* idx, float* dtable,
-                               int64_t rows, int D, int vocab, void* stream) {
+                               int64_t rows, int D, int vocab, int hot_index,
+                               float* hot_partial, void* stream) {
   if (rows == 0) return 0;
   MDLM_CHECK_ARG(dx && idx && dtable && rows > 0 && D > 0 && D % 4 == 0 && vocab > 0 && ((uintptr_t)dx & 15) == 0, "embed_grad: bad args");
-  const int64_t n = rows * (D / 4);
-  embed_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ST(stream)>>>(dx, idx, dtable, rows, D);
+  MDLM_CHECK_ARG(hot_index < vocab && (hot_index < 0 || hot_partial) && ((uintptr_t)hot_partial & 15) == 0,
+                 "embed_grad: hot_index needs a 16-byte aligned hot_partial workspace");
+  const int64_t nb = (rows + EG_ROWS - 1) / EG_ROWS;
+  MDLM_CHECK_ARG(nb < (1ll << 31), "embed_grad: too many rows");
+  embed_grad_kernel<<<(unsigned)nb, 256, 0, ST(stream)>>>(dx, idx, dtable, rows, D,
+                                                          hot_index >= 0 ? hot_index : -1,
+                                                          hot_index >= 0 ? hot_partial : nullptr);
   MDLM_LAUNCH_CHECK();
+  if (hot_index >= 0) {   // the hot row receives nothing through the atomics
+    colsum_reduce_kernel<<<dim3((unsigned)((D + 63) / 64), 1), 1024, 0, ST(stream)>>>(
+      hot_partial, dtable + (int64_t)hot_index * D, D, (int)nb);
+    MDLM_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -592,7 +751,9 @@ extern "C" int mdlm_subs_nll_bwd(const void* logits, int64_t ld, int dtype, cons
   MDLM_CHECK_ARG(rows > 0 && rows < (1ll << 31) && V > 0 && ld >= V && ldo >= V && ldo % 8 == 0 && ((uintptr_t)dlogits_bf16 & 15) == 0,
                  "subs_nll_bwd: ldo must be a multiple of 8 and >= V, output 16-byte aligned");
   MDLM_CHECK_ARG(mask_index >= 0 && mask_index < V, "subs_nll_bwd: bad mask index");
-  if (dtype == MDLM_BF16)
+  if (dtype == MDLM_BF16 && ld % 8 == 0 && ld >= ((V + 7) & ~7) && ((uintptr_t)logits & 15) == 0)
+    subs_nll_bwd_vec_kernel<<<(unsigned)rows, 256, 0, ST(stream)>>>((const bf16_t*)logits, ld, xt, x0, row_weight, (bf16_t*)dlogits_bf16, ldo, V, mask_index);
+  else if (dtype == MDLM_BF16)
     subs_nll_bwd_kernel<bf16_t><<<(unsigned)rows, 256, 0, ST(stream)>>>((const bf16_t*)logits, ld, xt, x0, row_weight, (bf16_t*)dlogits_bf16, ldo, V, mask_index);
   else if (dtype == MDLM_F32)
     subs_nll_bwd_kernel<float><<<(unsigned)rows, 256, 0, ST(stream)>>>((const float*)logits, ld, xt, x0, row_weight, (bf16_t*)dlogits_bf16, ldo, V, mask_index);

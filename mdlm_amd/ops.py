@@ -498,10 +498,15 @@ def transpose_bf16(x, out=None, ld_out=None):
   return out
 
 
-def embed_grad(dx, idx, dtable):
+def embed_grad(dx, idx, dtable, hot_index=-1, hot_partial=None):
+  """hot_index: a token id (the mask token) whose rows are summed in a fixed
+  order instead of through atomics; its table row is overwritten."""
   rows, D = dx.shape
+  if hot_index >= 0 and hot_partial is None:
+    hot_partial = torch.empty((rows + 127) // 128, D, dtype=torch.float32, device=dx.device)
   call('mdlm_embed_grad', dx.data_ptr(), idx.data_ptr(), dtable.data_ptr(),
-       int(rows), int(D), int(dtable.shape[0]), _stream())
+       int(rows), int(D), int(dtable.shape[0]), int(hot_index), _p(hot_partial),
+       _stream())
 
 
 def subs_nll_bwd(logits2d, xt, x0, row_weight, dlogits2d, V, mask_index):

@@ -178,21 +178,28 @@ class Trainer:
     inv_freq = bb.rotary_emb.inv_freq.float()
     fr = torch.einsum('i,j->ij', torch.arange(L, device=dev).float(), inv_freq)
     nblk = M // 32
+    Mp = (M + 255) // 256 * 256   # masked-row lists are padded to 256
     # split-K partial sums of the weight-gradient GEMMs (largest plan)
     n_part = max(ops.splitk_plan(n, k, M) * n * k
                  for n, k in ((3 * D, D), (D, D), (4 * D, D), (D, 4 * D), (Vp, D)))
     self._ws = dict(
       skp=e(n_part, dt=torch.float32),
-      key=key, blocks=blocks, x_last=e(M, D, dt=torch.float32), hf=e(M, D),
-      logits=torch.zeros(M, Vp, dtype=bf, device=dev), dlogits=e(M, Vp),
+      key=key, blocks=blocks, x_last=e(M, D, dt=torch.float32), hf=e(Mp, D),
+      logits=torch.zeros(Mp, Vp, dtype=bf, device=dev), dlogits=e(Mp, Vp),
+      samples=torch.arange(B, dtype=torch.int32, device=dev),
+      n_samples=torch.tensor([B], dtype=torch.int32, device=dev),
+      gather=torch.zeros(Mp + 256, dtype=torch.int32, device=dev),
+      scatter=torch.zeros(Mp + 256, dtype=torch.int32, device=dev),
+      n_out=torch.zeros(1, dtype=torch.int32, device=dev),
+      hot=e((M + 127) // 128, D, dt=torch.float32),
       cos=fr.cos().to(bf).float().contiguous(), sin=fr.sin().to(bf).float().contiguous(),
       dx=e(M, D, dt=torch.float32), d_md=e(M, D), d_m4=e(M, 4 * D), d_m4b=e(M, 4 * D),
       d_qkv=e(M, 3 * D), dq=e(M * D), dk=e(M * D), dv=e(M * D),
       delta=e(B * H * L, dt=torch.float32),
-      tA=e(max(Vp, 4 * D) * M), tB=e(4 * D * M), wT=e(max(Vp * D, 4 * D * D)),
+      tA=e(max(Vp, 4 * D) * Mp), tB=e(4 * D * Mp), wT=e(max(Vp * D, 4 * D * D)),
       wvT=torch.zeros(D, Vp, dtype=bf, device=dev),
       part3=e(nblk, 3, D, dt=torch.float32), part1=e(nblk, D, dt=torch.float32),
-      partc=e((M + 127) // 128, max(Vp, 4 * D), dt=torch.float32))
+      partc=e((Mp + 127) // 128, max(Vp, 4 * D), dt=torch.float32))
     return self._ws
 
   def _w16(self, name):
@@ -269,6 +276,9 @@ class Trainer:
     sigma, dsigma = model.noise(t)
     move_chance = 1 - torch.exp(-sigma[:, None])
     xt = model.q_xt(x0, move_chance, u=u_xt)
+    ops.masked_row_map(xt, ws['samples'], ws['n_samples'], L, model.mask_index,
+                       ws['gather'], ws['scatter'], ws['n_out'], pad=256)
+    n_pad = int(ws['n_out'].item())   # the only host read of the step (GPU queue still empty)
     sig_in = model._process_sigma(sigma[:, None])
     n_mod = B if model.time_conditioning else 1
     with torch.enable_grad():
@@ -305,32 +315,49 @@ class Trainer:
       x_next = ws['blocks'][i + 1]['x_in'] if i + 1 < bb.n_blocks else ws['x_last']
       ops.dropout_gate_residual_fwd(a['y2'], mod[:, 5 * D:6 * D], a['x_mid'], x_next, L, n_mod,
                                     ld6, p, seed, a['drop'][1])
+    # ---- output layer and loss on the MASKED rows only ---------------------------
+    # SUBS gives an unmasked position log p = 0 whatever its logits
+    # (diffusion.py:270-277), so only masked rows carry loss or gradient: the
+    # final LN/modulate gathers them into a dense (n_pad, D) matrix (n_pad: count
+    # rounded up to 256, known since q_xt) and the vocabulary projection, its
+    # softmax backward and both of its backward GEMMs run on those rows alone.
     modf = md[-1]
-    ops.ln_modulate(ws['x_last'], self._p32('output_layer.norm_final.weight'), modf[:, 0:D],
-                    modf[:, D:2 * D], ws['hf'], L, n_mod, ld2)
-    logits = ws['logits'][:, :V]
-    ops.gemm_bf16(ws['hf'], self._w16('output_layer.linear.weight'), logits, EPI_STORE,
-                  bias=self._p32('output_layer.linear.bias'), ldc=ws['logits'].stride(0))
-    # ---- loss (diffusion.py:884-916) ------------------------------------------
+    hfc, lgc, dlc = ws['hf'][:n_pad], ws['logits'][:n_pad], ws['dlogits'][:n_pad]
     weight = dsigma / torch.expm1(sigma)
-    nlls = ops.subs_nll(logits.view(B, L, V), xt, x0, weight, model.mask_index,
-                        attn_mask=attention_mask)
+    nlls = torch.zeros(B, L, dtype=torch.float32, device=self.dev)
+    if n_pad:
+      sc = ws['scatter'][:n_pad].long()
+      valid = sc >= 0
+      scc = sc.clamp(min=0)
+      x0_c = x0.reshape(-1)[scc].contiguous()
+      xt_c = torch.where(valid, torch.full_like(x0_c, model.mask_index), x0_c)
+      w_c = ((weight[:, None] * attention_mask).reshape(-1)[scc] * valid).contiguous()
+      ops.ln_modulate(ws['x_last'], self._p32('output_layer.norm_final.weight'), modf[:, 0:D],
+                      modf[:, D:2 * D], hfc, L, n_mod, ld2, n_rows_dev=ws['n_out'],
+                      row_gather=ws['gather'], rows=n_pad)
+      ops.gemm_bf16(hfc, self._w16('output_layer.linear.weight'), lgc[:, :V], EPI_STORE,
+                    bias=self._p32('output_layer.linear.bias'), ldc=lgc.stride(0))
+      # ---- loss (diffusion.py:884-916) ----------------------------------------
+      nll_c = ops.subs_nll(lgc[:, :V], xt_c[:, None], x0_c[:, None], w_c,
+                           model.mask_index)
+      nlls.view(-1).index_add_(0, scc, nll_c.view(-1) * valid)
     sums = ops.nll_sums(nlls, attention_mask)
     token_nll = (sums[0] / sums[1]).float()
-    row_w = (weight[:, None] * attention_mask / attention_mask.sum()).reshape(-1).contiguous()
     # ---- backward --------------------------------------------------------------
     self.G.zero_()
-    dl = ws['dlogits'][:, :V]
-    ops.subs_nll_bwd(logits, xt.view(-1), x0.reshape(-1).contiguous(), row_w, dl, V,
-                     model.mask_index)
-    # output layer: logits = hf Wv^T + bv (rows of dWv beyond V stay in the partials)
-    ops.colsum_bf16(dl, partial=ws['partc'], out=self._g('output_layer.linear.bias'))
-    dlT = self._transpose(ws['dlogits'], ws['tA'])
-    hfT = self._transpose(ws['hf'], ws['tB'])
-    ops.gemm_bf16_splitk(dlT, hfT, self._g('output_layer.linear.weight'), ws['skp'])
-    ops.transpose_bf16(self._w16('output_layer.linear.weight'), out=ws['wvT'][:, :V],
-                       ld_out=ws['wvT'].stride(0))
-    ops.gemm_bf16(ws['dlogits'], ws['wvT'], ws['d_md'], EPI_STORE)
+    ws['d_md'].zero_()
+    if n_pad:
+      row_w = (w_c / attention_mask.sum()).contiguous()
+      ops.subs_nll_bwd(lgc[:, :V], xt_c, x0_c, row_w, dlc[:, :V], V, model.mask_index)
+      # logits = hf Wv^T + bv (rows of dWv beyond V stay in the split-K partials)
+      ops.colsum_bf16(dlc[:, :V], partial=ws['partc'], out=self._g('output_layer.linear.bias'))
+      dlT = self._transpose(dlc, ws['tA'])
+      hfT = self._transpose(hfc, ws['tB'])
+      ops.gemm_bf16_splitk(dlT, hfT, self._g('output_layer.linear.weight'), ws['skp'])
+      ops.transpose_bf16(self._w16('output_layer.linear.weight'), out=ws['wvT'][:, :V],
+                         ld_out=ws['wvT'].stride(0))
+      # d(hf) rows go back to their positions; unmasked rows keep the zero
+      ops.gemm_bf16(dlc, ws['wvT'], ws['d_md'], EPI_STORE, out_row_map=ws['scatter'])
     dx = ws['dx']
     nb32 = L // 32
     red3 = torch.empty(n_mod, 3, D, device=self.dev)
@@ -385,7 +412,8 @@ class Trainer:
       with torch.enable_grad():
         torch.autograd.backward([mods[i]], [dm], retain_graph=i > 0)
       self.buckets.launch(self.bucket_ids[i])
-    ops.embed_grad(dx, xt.view(-1), self._g('vocab_embed.embedding'))
+    ops.embed_grad(dx, xt.view(-1), self._g('vocab_embed.embedding'),
+                   hot_index=model.mask_index, hot_partial=ws['hot'])
     self.buckets.launch(len(self.buckets.slices) - 1)
     if not last:
       if self.A is None:

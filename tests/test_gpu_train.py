@@ -110,6 +110,12 @@ def test_gelu_transpose_colsum_embed(ops):
   assert torch.equal(ops.transpose_bf16(xp[:, :322]).cpu(), xp[:, :322].t().contiguous().cpu())
   xb = _bf(torch.randn(6, 64, 128)).cuda()
   assert torch.equal(ops.transpose_bf16(xb).cpu(), xb.transpose(1, 2).contiguous().cpu())
+  # 16-byte path: R, C, leading dimensions multiples of 8 (ragged 64x64 tiles, padded rows)
+  for R, C, ld in ((200, 328, 328), (1024, 768, 768), (136, 72, 96)):
+    xv = _bf(torch.randn(R, ld)).cuda()
+    assert torch.equal(ops.transpose_bf16(xv[:, :C]).cpu(), xv[:, :C].t().contiguous().cpu()), (R, C)
+  xb = _bf(torch.randn(3, 72, 200)).cuda()
+  assert torch.equal(ops.transpose_bf16(xb).cpu(), xb.transpose(1, 2).contiguous().cpu())
   # column sums
   z = _bf(torch.randn(1000, 770))
   assert _rel(ops.colsum_bf16(z.cuda()), z.float().sum(0)) < 1e-5
@@ -120,6 +126,15 @@ def test_gelu_transpose_colsum_embed(ops):
   dt = torch.zeros(50, 64, device='cuda')
   ops.embed_grad(dx.cuda(), idx.cuda(), dt)
   assert (dt.cpu() - ref).abs().max().item() < 1e-4
+  # hot row (the mask token): summed in a fixed order, written not added
+  idx[::2] = 7
+  ref = torch.zeros(50, 64).index_add_(0, idx, dx)
+  dt = torch.zeros(50, 64, device='cuda'); dt[7] = 123.0
+  ops.embed_grad(dx.cuda(), idx.cuda(), dt, hot_index=7)
+  assert (dt.cpu() - ref).abs().max().item() < 1e-4
+  dt2 = torch.zeros(50, 64, device='cuda')
+  ops.embed_grad(dx.cuda(), idx.cuda(), dt2, hot_index=7)
+  assert torch.equal(dt2[7], dt[7])
 
 
 def test_qkv_grad_pack(ops):
