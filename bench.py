@@ -135,8 +135,8 @@ def train_bench(args):
   forward + backward + all-reduce + optimizer/EMA over one global batch."""
   from mdlm_amd.train import Trainer
   rank, local_rank, world = mdist.init()
-  torch.cuda.set_device(local_rank)
-  dev = torch.device('cuda', local_rank)
+  torch.cuda.set_device(mdist.local_device(local_rank))
+  dev = torch.device('cuda', mdist.local_device(local_rank))
   gb = args.global_batch
   cfg = load_config(['model=small', 'data=lm1b', 'model.length=128',
                      f'loader.global_batch_size={gb}', f'trainer.devices={world}'])
@@ -194,6 +194,9 @@ def main():
   ap.add_argument('--no-policy-compare', action='store_true')
   ap.add_argument('--no-eval', action='store_true')
   args = ap.parse_args()
+  if os.environ.get('MDLM_FAULT_DUMP_S'):   # debugging aid: Python stacks of a stuck rank
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ['MDLM_FAULT_DUMP_S']), exit=True)
   if args.workload == 'train':
     return train_bench(args)
 
@@ -202,8 +205,8 @@ def main():
     if args.gpus > 1:
       raise SystemExit(f'--gpus {args.gpus} needs torchrun with {args.gpus} ranks '
                        f'(WORLD_SIZE={world})')
-  torch.cuda.set_device(local_rank)
-  dev = torch.device('cuda', local_rank)
+  torch.cuda.set_device(mdist.local_device(local_rank))
+  dev = torch.device('cuda', mdist.local_device(local_rank))
 
   cfg = load_config([f'model={args.model}', f'loader.eval_batch_size={args.batch}',
                      f'sampling.steps={args.T}', f'sampling.cache_policy={args.cache_policy}',

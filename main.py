@@ -165,7 +165,7 @@ def main(argv=None):
   config = load_config(argv, world_size=world)
   if not torch.cuda.is_available():
     raise SystemExit('mdlm_amd runs on an MI355X (ROCm) device; there is no CPU fallback')
-  torch.cuda.set_device(local_rank)
+  torch.cuda.set_device(mdist.local_device(local_rank))
   torch.manual_seed(config.seed)
   tokenizer = get_tokenizer(config)
   if config.mode == 'sample_eval':

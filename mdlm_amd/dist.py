@@ -15,16 +15,29 @@ def env_rank():
           int(os.environ.get('WORLD_SIZE', 1)))
 
 
+def local_device(local_rank):
+  """GPU index of this rank: LOCAL_RANK on a node with one GPU per rank.  With
+  fewer GPUs than ranks (rehearsing N ranks on a one-GPU box over gloo) ranks
+  wrap around the visible devices."""
+  n = torch.cuda.device_count()
+  return local_rank % n if n else 0
+
+
 def init(backend=None):
   """Initialise the default process group from the torchrun environment.
-  Returns (rank, local_rank, world_size).  No-op for world_size == 1."""
+  Returns (rank, local_rank, world_size).  No-op for world_size == 1.
+  MDLM_DIST_BACKEND overrides the backend (gloo: rehearsals and CPU tests)."""
   rank, local_rank, world = env_rank()
   if world > 1 and not dist.is_initialized():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:
-      backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+      backend = os.environ.get('MDLM_DIST_BACKEND') or (
+        'nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
+      if world > torch.cuda.device_count():
+        raise RuntimeError(f'{world} RCCL ranks need {world} GPUs '
+                           f'({torch.cuda.device_count()} visible)')
       torch.cuda.set_device(local_rank)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
   return rank, local_rank, world
@@ -40,7 +53,10 @@ def rank():
 
 def barrier():
   if dist.is_initialized():
-    dist.barrier()
+    if dist.get_backend() == 'nccl':
+      dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
+      dist.barrier()
 
 
 def shard_indices(n_items, rank_, world):

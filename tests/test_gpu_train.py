@@ -2,6 +2,7 @@
 hand-written backward against torch autograd of the CPU oracle's fp32 op on the
 same seeded inputs.  bf16 tolerance 2e-2 (relative L2), fp32 paths 1e-4."""
 import math
+import os
 
 import pytest
 import torch
@@ -403,3 +404,63 @@ def test_gemm_splitk(ops, M, N, K, splits):
   assert torch.equal(out, out2)
   if splits is None:
     assert s == 4   # 9 tiles of 256x256; each range keeps >= 512 tokens: 2048 / 512 = 4
+
+
+_DDP_WORKER = r'''
+import os, sys, torch
+root = sys.argv[1]; out = sys.argv[2]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'tests')); sys.path.insert(0, os.path.join(root, 'oracle'))
+from mdlm_amd import dist as mdist
+rank, local_rank, world = mdist.init(backend='gloo')
+torch.cuda.set_device(mdist.local_device(local_rank))
+import test_gpu_train as T
+model, cfg, p, tr = T._make_trainer(0.0)
+assert tr.world == 2 and tr.buckets.enabled
+B, L = 4, cfg.model.length
+x0, attn, t, u = T._batch(B, L, seed=21 + rank)
+for _ in range(2):   # second step has a non-zero learning rate
+  tr.forward_backward(x0.cuda(), attn.cuda(), t=t.cuda(), u_xt=u.cuda())
+  tr.optimizer_step()
+torch.cuda.synchronize()
+torch.save({'P': tr.P.cpu(), 'G': tr.G.cpu(), 'norm': tr.grad_norm()}, out + f'.{rank}')
+mdist.barrier()
+'''
+
+
+def test_ddp_two_ranks_match_accumulation(ops, tmp_path):
+  """DDP (configs/strategy/ddp.yaml): two ranks, each with its own micro-batch,
+  bucketed gradient all-reduce on the side stream (gloo here, RCCL on a node)
+  -> the same parameters as one process accumulating both micro-batches."""
+  import socket, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  script = tmp_path / 'ddp_worker.py'
+  script.write_text(_DDP_WORKER)
+  out = str(tmp_path / 'res')
+  procs = []
+  for r in range(2):
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    procs.append(subprocess.Popen([sys.executable, str(script), root, out], env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+  outs = [p.communicate(timeout=110) for p in procs]
+  for p, (o, e) in zip(procs, outs):
+    assert p.returncode == 0, e[-3000:]
+  r0, r1 = (torch.load(out + f'.{r}', weights_only=True) for r in range(2))
+  assert torch.equal(r0['P'], r1['P']) and torch.equal(r0['G'], r1['G'])   # replicas stay in step
+  model, cfg, p, tr = _make_trainer(0.0)
+  B, L = 4, cfg.model.length
+  batches = [_batch(B, L, seed=21 + r) for r in range(2)]
+  for _ in range(2):
+    for i, (x0, attn, t, u) in enumerate(batches):
+      tr.forward_backward(x0.cuda(), attn.cuda(), t=t.cuda(), u_xt=u.cuda(),
+                          accumulate=i > 0, last=i == 1)
+    tr.optimizer_step()
+  assert abs(tr.grad_norm() - r0['norm']) < 1e-4 * r0['norm']
+  # summed gradients agree to fp32 rounding (atomics in the embedding gradient
+  # are order-dependent); Adam turns a rounding-level gradient into a full-size
+  # update where the true gradient cancels to ~0, hence the fraction bound
+  g_ref, g_ddp = tr.G.cpu().double(), r0['G'].double()
+  assert (g_ref - g_ddp).norm() < 1e-5 * g_ref.norm()
+  diff = (tr.P.cpu() - r0['P']).abs()
+  assert (diff > 2e-5).float().mean().item() < 1e-3, diff.max().item()
