@@ -64,7 +64,14 @@ class GradBuckets:
       self.flat[a:b] += self.carry[a:b]
     if not self.enabled:
       return
-    if self.stream is not None:
+    if self.stream is not None and dist.get_backend(self.group) != 'nccl':
+      # rehearsal of N ranks on one card over gloo: staged through host memory,
+      # synchronously (gloo's own device path stalls on large slices when both
+      # ranks share a GPU); the RCCL path below is the product path
+      host = self.flat[a:b].cpu()
+      dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+      self.flat[a:b].copy_(host)
+    elif self.stream is not None:
       self.stream.wait_stream(torch.cuda.current_stream())
       with torch.cuda.stream(self.stream):
         self.work.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM,
