@@ -9,9 +9,15 @@ A "step" is one full `restore_model_and_sample(num_steps=1000)` over one batch
 operands, GPT-2-shaped vocab 50,258, seeded synthetic weights, all-mask prior).
 Ranks are independent replicas (seed + rank); no data-path collective.  Rank 0
 prints ONE JSON line: metric = ddpm_cache samples/sec (whole job), plus
-`roofline` for the dominant kernel (vocab-projection bf16 MFMA GEMM, timed live
-with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle timed
-on this box's host cores on a bounded sample).
+`roofline` for the dominant kernel (the gate/residual bf16 MFMA GEMM
+instantiation, timed live with HIP events on the launch stream; the vocab
+projection is reported beside it) and `cpu_baseline` (the CPU oracle timed on
+this box's host cores on a bounded sample).
+
+Other workloads of BASELINE.json's config list, each printing its own JSON line
+(never the driver's default): `--workload train` (configs[4], LM1B training
+step tokens/s) and `--workload semi_ar` (configs[3], 2048-token semi-AR
+sequences/s).  `MDLM_DIST_BACKEND=gloo` rehearses N ranks on a one-GPU box.
 """
 import argparse
 import json
@@ -179,9 +185,52 @@ def train_bench(args):
   mdist.barrier()
 
 
+def semi_ar_bench(args):
+  """BASELINE.json configs[3]: semi-autoregressive generation (README recipe:
+  L=1024 windows, stride 512, 2 extra strides -> 2048 tokens per sequence,
+  dt = 1/1000), batch 64 per GPU, replicas sharded by sample (no collective).
+  A step = one restore_model_and_semi_ar_sample over one batch."""
+  rank, local_rank, world = mdist.init()
+  torch.cuda.set_device(mdist.local_device(local_rank))
+  dev = torch.device('cuda', mdist.local_device(local_rank))
+  cfg = load_config(['model=small', f'loader.eval_batch_size={args.batch}',
+                     f'sampling.steps={args.T}', 'sampling.semi_ar=True',
+                     'sampling.stride_length=512', 'sampling.num_strides=2',
+                     'sampling.fast_math=true', f'trainer.devices={world}'])
+  model = build_model(cfg, seed=1)
+  model.seed_rng(mdist.rank_seed(cfg.seed, rank))
+  B, L = args.batch, cfg.model.length
+  run = lambda: model.restore_model_and_semi_ar_sample(
+    stride_length=cfg.sampling.stride_length, num_strides=cfg.sampling.num_strides,
+    dt=1 / args.T)
+  for _ in range(args.warmup):
+    run()
+  torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    nfe_steps, _, seq_lens = run()
+  torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
+  el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+  n_tok = L + cfg.sampling.num_strides * cfg.sampling.stride_length
+  out = {'metric': 'semi-AR generation sequences/sec (2048 tokens, stride 512, T=1000 per window)',
+         'value': round(world * B * args.steps / el, 4), 'unit': 'sequences/s', 'n_gpus': world,
+         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(el / args.steps * 1e3, 1),
+         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
+         'data': 'synthetic',
+         'config': {'workload': f'semi-AR sample_subs_guidance, DiT-small, window L={L}, stride 512, '
+                                f'num_strides 2 -> {n_tok} tokens, dt=1/{args.T}, batch={B}/GPU',
+                    'parallelism': f'replicas x{world}'},
+         'tokens_per_sec': round(world * B * n_tok * args.steps / el, 1),
+         'sec_per_sequence_at_this_batch': round(el / args.steps / B, 4),
+         'steps_with_change': int(nfe_steps)}
+  if rank == 0:
+    print(json.dumps(out), flush=True)
+  mdist.barrier()
+
+
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--workload', default='sample', choices=['sample', 'train'])
+  ap.add_argument('--workload', default='sample', choices=['sample', 'train', 'semi_ar'])
   ap.add_argument('--global-batch', type=int, default=512)
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=2)
@@ -199,6 +248,8 @@ def main():
     faulthandler.dump_traceback_later(int(os.environ['MDLM_FAULT_DUMP_S']), exit=True)
   if args.workload == 'train':
     return train_bench(args)
+  if args.workload == 'semi_ar':
+    return semi_ar_bench(args)
 
   rank, local_rank, world = mdist.init()
   if world != args.gpus:
