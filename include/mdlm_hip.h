@@ -283,6 +283,17 @@ int mdlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw
 int mdlm_splitk_reduce(const float* partials, float* out, int64_t n, int splits,
                        int64_t split_stride, void* stream);
 
+/* The same weight gradient on TOKEN-MAJOR operands, as the forward / backward
+ * kernels leave them (no transposed copies): dY (T, N) ld ldy, X (T, K) ld ldx,
+ * both bf16;  partials[s][N][K] = sum over the tokens of range s of
+ * dY[t, n] * X[t, k]  (fp32; ranges of ceil(T/64/splits) 64-token slabs, the
+ * last may be shorter).  bias_partials (optional): [s][N] = sum_t dY[t, n], the
+ * bias gradient of the same Linear.  N % 256 == 0, K % 256 == 0, T % 64 == 0.
+ * Finish both with mdlm_splitk_reduce. */
+int mdlm_gemm_tn_splitk(const void* dY, int64_t ldy, const void* X, int64_t ldx,
+                        float* partials, float* bias_partials, int64_t T, int N,
+                        int K, int splits, void* stream);
+
 /* Bidirectional attention, dit.py:265-275 (flash_attn_varlen_qkvpacked_func,
  * equal lengths, no dropout, softmax scale 1/sqrt(64)): q,k (n_seq,H,L,64)
  * bf16, vt (n_seq,H,64,L) bf16 -> out (n_seq*L, H*64) bf16.  L % 128 == 0. */
@@ -381,10 +392,15 @@ int mdlm_gelu_bwd(const void* dact_bf16, const void* pre_bf16, void* dpre_bf16,
                   int64_t n, void* stream);
 
 /* out[b][c][r] = in[b][r][c], bf16 (operand layout for the backward GEMMs;
- * no reference counterpart: torch.matmul takes strided operands). */
+ * no reference counterpart: torch.matmul takes strided operands).
+ * colsum_partial (optional; batch 1, R, C and leading dimensions multiples of
+ * 8): partial[i][c] = fp32 sum of rows 64 i .. 64 i + 63 of column c, i.e. the
+ * first stage of the bias gradient of the Linear whose dY is transposed here
+ * (ceil(R/64) x C floats; finish with mdlm_colsum_reduce). */
 int mdlm_transpose_bf16(const void* in, int64_t ld_in, int64_t batch_stride_in,
                         void* out, int64_t ld_out, int64_t batch_stride_out,
-                        int R, int C, int batch, void* stream);
+                        int R, int C, int batch, float* colsum_partial,
+                        void* stream);
 
 /* dtable[idx[r]] += dx[r]: backward of dit.py:298-299.  fp32 atomics, except
  * for rows whose index is hot_index (>= 0: the mask token, which about half of

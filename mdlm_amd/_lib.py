@@ -61,10 +61,11 @@ SIGNATURES = {
   'mdlm_dropout_gate_residual_bwd': [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i64, _f32, _u64, _u64, _vp],
   'mdlm_gelu_fwd': [_vp, _vp, _i64, _vp],
   'mdlm_gelu_bwd': [_vp, _vp, _vp, _i64, _vp],
-  'mdlm_transpose_bf16': [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+  'mdlm_transpose_bf16': [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp],
   'mdlm_embed_grad': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp],
   'mdlm_subs_nll_bwd': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
   'mdlm_gemm_bf16_splitk': [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _i32, _vp],
+  'mdlm_gemm_tn_splitk': [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
   'mdlm_splitk_reduce': [_vp, _vp, _i64, _i32, _i64, _vp],
   'mdlm_grad_sumsq': [_vp, _i64, _vp, _vp, _vp],
   'mdlm_adamw_ema': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp, _f32, _f32, _vp],

@@ -292,9 +292,14 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(
 // writes per store instruction then fall into eight different bank groups),
 // read back as whole 16-byte chunks: eight lanes store 128 contiguous bytes
 // of one output row.
+//
+// colsum_partial (optional, batch 1): partial[blockIdx.y][c] = sum of the tile's
+// 64 rows of column c in fp32 (the bias gradient of the Linear whose dY is being
+// transposed), added up by mdlm_colsum_reduce: the separate column-sum pass over
+// dY is then not needed.
 __global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(
     const bf16_t* __restrict__ in, int64_t ld_in, int64_t bs_in, bf16_t* __restrict__ out,
-    int64_t ld_out, int64_t bs_out, int R, int C) {
+    int64_t ld_out, int64_t bs_out, int R, int C, float* __restrict__ colsum_partial) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 64];
   const bf16_t* ib = in + (int64_t)blockIdx.z * bs_in;
   bf16_t* ob = out + (int64_t)blockIdx.z * bs_out;
@@ -324,9 +329,16 @@ __global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(
   for (int it = 0; it < 2; ++it) {
     const int cl = w * 16 + it * 8 + (lane >> 3), rc = lane & 7;
     const int c = c0 + cl, r = r0 + rc * 8;
-    if (c < C && r < R) {
-      const uint4 o = *reinterpret_cast<const uint4*>(tile + cl * 64 + ((rc ^ ((cl >> 3) & 7)) << 3));
-      *reinterpret_cast<uint4*>(ob + (int64_t)c * ld_out + r) = o;
+    const uint4 o = *reinterpret_cast<const uint4*>(tile + cl * 64 + ((rc ^ ((cl >> 3) & 7)) << 3));
+    if (c < C && r < R) *reinterpret_cast<uint4*>(ob + (int64_t)c * ld_out + r) = o;
+    if (colsum_partial) {   // rows past R were loaded as zeros
+      const unsigned u[4] = {o.x, o.y, o.z, o.w};
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        sm += __uint_as_float(u[j] << 16) + __uint_as_float(u[j] & 0xffff0000u);
+      sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4);
+      if (rc == 0 && c < C) colsum_partial[(int64_t)blockIdx.y * C + c] = sm;
     }
   }
 }
@@ -690,7 +702,7 @@ extern "C" int mdlm_gelu_bwd(const void* dact_bf16, const void* pre_bf16, void* 
 
 extern "C" int mdlm_transpose_bf16(const void* in, int64_t ld_in, int64_t batch_stride_in,
                                    void* out, int64_t ld_out, int64_t batch_stride_out,
-                                   int R, int C, int batch, void* stream) {
+                                   int R, int C, int batch, float* colsum_partial, void* stream) {
   if (R == 0 || C == 0 || batch == 0) return 0;
   MDLM_CHECK_ARG(in && out && R > 0 && C > 0 && batch > 0 && ld_in >= C && ld_out >= R, "transpose_bf16: bad args");
   MDLM_CHECK_ARG((R + 63) / 64 < 65536 && batch < 65536, "transpose_bf16: too large");
@@ -698,9 +710,11 @@ extern "C" int mdlm_transpose_bf16(const void* in, int64_t ld_in, int64_t batch_
   const bool vec = R % 8 == 0 && C % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 &&
                    batch_stride_in % 8 == 0 && batch_stride_out % 8 == 0 &&
                    (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+  MDLM_CHECK_ARG(!colsum_partial || (vec && batch == 1),
+                 "transpose_bf16: colsum_partial needs batch 1 and the 16-byte path (R, C, ld %% 8 == 0)");
   if (vec)
     transpose_bf16_vec_kernel<<<grid, 256, 0, ST(stream)>>>(
-      (const bf16_t*)in, ld_in, batch_stride_in, (bf16_t*)out, ld_out, batch_stride_out, R, C);
+      (const bf16_t*)in, ld_in, batch_stride_in, (bf16_t*)out, ld_out, batch_stride_out, R, C, colsum_partial);
   else
     transpose_bf16_kernel<<<grid, 256, 0, ST(stream)>>>(
       (const bf16_t*)in, ld_in, batch_stride_in, (bf16_t*)out, ld_out, batch_stride_out, R, C);

@@ -383,6 +383,50 @@ def gemm_bf16_splitk(A, W, out, partials, splits=None):
   return out
 
 
+def tn_splitk_plan(N, K, T, max_splits=64, min_slabs=16):
+  """Token ranges for mdlm_gemm_tn_splitk: fills the 256 persistent workgroups
+  evenly (tiles * splits close below a multiple of 256) while a range keeps
+  >= min_slabs 64-token slabs; cost model in slab units (a tile's 256 KiB
+  epilogue ~ 5 slabs; reducing one more partial plane ~ 0.35 slabs per nine
+  tiles of output)."""
+  tiles = (N // 256) * (K // 256)
+  slabs = T // 64
+  best, best_cost = 1, None
+  for s in range(1, max_splits + 1):
+    per = -(-slabs // s)
+    if s > 1 and (per < min_slabs or (s - 1) * per >= slabs):
+      continue
+    rounds = -(-tiles * s // 256)
+    cost = rounds * (per + 5) + 0.35 * s * tiles / 9
+    if best_cost is None or cost < best_cost:
+      best, best_cost = s, cost
+  return best
+
+
+def gemm_tn_splitk(dY, X, out, partials, bias_out=None, bias_partials=None, splits=None):
+  """out (N, K) fp32 = dY (T, N)^T @ X (T, K), token-major bf16 operands read in
+  place (mdlm_gemm_tn_splitk + mdlm_splitk_reduce); bias_out (N) = column sums
+  of dY.  `out` may hold fewer than N rows (the leading rows are written)."""
+  T, N = dY.shape
+  K = X.shape[1]
+  assert X.shape[0] == T and dY.dtype == torch.bfloat16 and X.dtype == torch.bfloat16
+  assert dY.stride(1) == 1 and X.stride(1) == 1 and out.is_contiguous()
+  if splits is None:
+    splits = tn_splitk_plan(N, K, T)
+  assert partials.numel() >= splits * N * K and partials.dtype == torch.float32
+  if bias_out is not None:
+    assert bias_partials is not None and bias_partials.numel() >= splits * N
+  call('mdlm_gemm_tn_splitk', dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0),
+       partials.data_ptr(), _p(bias_partials if bias_out is not None else None),
+       int(T), int(N), int(K), int(splits), _stream())
+  call('mdlm_splitk_reduce', partials.data_ptr(), out.data_ptr(), out.numel(),
+       int(splits), int(N * K), _stream())
+  if bias_out is not None:
+    call('mdlm_splitk_reduce', bias_partials.data_ptr(), bias_out.data_ptr(),
+         bias_out.numel(), int(splits), int(N), _stream())
+  return out
+
+
 def attn_fwd(q, k, vt, out, n_seq, H, L, n_seq_dev=None):
   call('mdlm_attn_fwd', q.data_ptr(), k.data_ptr(), vt.data_ptr(),
        out.data_ptr(), int(n_seq), int(H), int(L), _p(n_seq_dev), _stream())
@@ -478,9 +522,10 @@ def gelu_bwd(dact, pre, dpre):
   return dpre
 
 
-def transpose_bf16(x, out=None, ld_out=None):
+def transpose_bf16(x, out=None, ld_out=None, colsum_partial=None):
   """(R, C) or (batch, R, C) bf16 -> (C, R) / (batch, C, R); the input may have
-  a padded leading dimension (stride(-2) >= C)."""
+  a padded leading dimension (stride(-2) >= C).  colsum_partial: fp32
+  (ceil(R/64), C) workspace that receives per-64-row column sums (2-D input)."""
   if x.dim() == 2:
     R, C = x.shape
     batch, bs_in = 1, 0
@@ -494,7 +539,7 @@ def transpose_bf16(x, out=None, ld_out=None):
   bs_out = out.stride(0) if out.dim() == 3 else 0
   call('mdlm_transpose_bf16', x.data_ptr(), x.stride(-2), int(bs_in),
        out.data_ptr(), int(ld_o), int(bs_out), int(R), int(C), int(batch),
-       _stream())
+       _p(colsum_partial), _stream())
   return out
 
 

@@ -187,10 +187,12 @@ class Trainer:
     nblk = M // 32
     Mp = (M + 255) // 256 * 256   # masked-row lists are padded to 256
     # split-K partial sums of the weight-gradient GEMMs (largest plan)
-    n_part = max(ops.splitk_plan(n, k, M) * n * k
-                 for n, k in ((3 * D, D), (D, D), (4 * D, D), (D, 4 * D), (Vp, D)))
+    shapes = ((3 * D, D), (D, D), (4 * D, D), (D, 4 * D), (Vp, D))
+    n_part = max(max(ops.splitk_plan(n, k, M), ops.tn_splitk_plan(n, k, Mp) if n % 256 == 0 and k % 256 == 0 else 1,
+                     ops.tn_splitk_plan(n, k, Mp // 2) if n % 256 == 0 and k % 256 == 0 else 1) * n * k
+                 for n, k in shapes)
     self._ws = dict(
-      skp=e(n_part, dt=torch.float32),
+      skp=e(n_part, dt=torch.float32), skb=e(64 * max(Vp, 4 * D), dt=torch.float32),
       key=key, blocks=blocks, x_last=e(M, D, dt=torch.float32), hf=e(Mp, D),
       logits=torch.zeros(Mp, Vp, dtype=bf, device=dev), dlogits=e(Mp, Vp),
       samples=torch.arange(B, dtype=torch.int32, device=dev),
@@ -206,7 +208,8 @@ class Trainer:
       tA=e(max(Vp, 4 * D) * Mp), tB=e(4 * D * Mp), wT=e(max(Vp * D, 4 * D * D)),
       wvT=torch.zeros(D, Vp, dtype=bf, device=dev),
       part3=e(nblk, 3, D, dt=torch.float32), part1=e(nblk, D, dt=torch.float32),
-      partc=e((Mp + 127) // 128, max(Vp, 4 * D), dt=torch.float32))
+      bias_v=e(Vp, dt=torch.float32),
+      partc=e((Mp + 63) // 64, max(Vp, 4 * D), dt=torch.float32))
     return self._ws
 
   def _w16(self, name):
@@ -231,22 +234,41 @@ class Trainer:
                          bb.output_layer.adaLN_modulation.bias))
     return mods
 
-  def _transpose(self, x, buf):
+  def _transpose(self, x, buf, colsum_out=None, ws=None):
+    """x^T into `buf`; with colsum_out also the fp32 column sums of x (the bias
+    gradient), whose first stage rides on the transpose's pass over x."""
     R, C = x.shape
     out = buf[:R * C].view(C, R)
-    return ops.transpose_bf16(x, out=out)
+    if colsum_out is None:
+      return ops.transpose_bf16(x, out=out)
+    nb = (R + 63) // 64
+    part = ws['partc'].view(-1)[:nb * C]
+    ops.transpose_bf16(x, out=out, colsum_partial=part)
+    ops.colsum_reduce(part, colsum_out, C, nb, 1)
+    return out
 
   def _wt(self, name, ws):
     w = self._w16(name)
     return self._transpose(w, ws['wT'])
 
+  def _weight_grad(self, dy, a, dw, db, ws):
+    """dw = dy^T a (+ db = column sums of dy).  Shapes that tile by 256 read the
+    token-major operands in place (mdlm_gemm_tn_splitk); others go through
+    transposed copies and the K-contiguous split-K GEMM."""
+    T, N = dy.shape
+    K = a.shape[1]
+    if N % 256 == 0 and K % 256 == 0 and T % 64 == 0:
+      s = ops.tn_splitk_plan(N, K, T)
+      if s * N * K <= ws['skp'].numel() and s * N <= ws['skb'].numel():
+        ops.gemm_tn_splitk(dy, a, dw, ws['skp'], bias_out=db, bias_partials=ws['skb'], splits=s)
+        return
+    dyT = self._transpose(dy, ws['tA'], db, ws)
+    aT = self._transpose(a, ws['tB'])
+    ops.gemm_bf16_splitk(dyT, aT, dw, ws['skp'])
+
   def _linear_bwd(self, dy, a, wname, bname, ws, da_out):
     """y = a W^T (+ b): G[W] = dy^T a, G[b] = colsum(dy), da = dy W."""
-    dyT = self._transpose(dy, ws['tA'])
-    aT = self._transpose(a, ws['tB'])
-    ops.gemm_bf16_splitk(dyT, aT, self._g(wname), ws['skp'])
-    if bname is not None:
-      ops.colsum_bf16(dy, partial=ws['partc'], out=self._g(bname))
+    self._weight_grad(dy, a, self._g(wname), None if bname is None else self._g(bname), ws)
     if da_out is not None:
       ops.gemm_bf16(dy, self._wt(wname, ws), da_out, EPI_STORE)
     return da_out
@@ -357,10 +379,8 @@ class Trainer:
       row_w = (w_c / attention_mask.sum()).contiguous()
       ops.subs_nll_bwd(lgc[:, :V], xt_c, x0_c, row_w, dlc[:, :V], V, model.mask_index)
       # logits = hf Wv^T + bv (rows of dWv beyond V stay in the split-K partials)
-      ops.colsum_bf16(dlc[:, :V], partial=ws['partc'], out=self._g('output_layer.linear.bias'))
-      dlT = self._transpose(dlc, ws['tA'])
-      hfT = self._transpose(hfc, ws['tB'])
-      ops.gemm_bf16_splitk(dlT, hfT, self._g('output_layer.linear.weight'), ws['skp'])
+      self._weight_grad(dlc, hfc, self._g('output_layer.linear.weight'), ws['bias_v'], ws)
+      self._g('output_layer.linear.bias').copy_(ws['bias_v'][:V])
       ops.transpose_bf16(self._w16('output_layer.linear.weight'), out=ws['wvT'][:, :V],
                          ld_out=ws['wvT'].stride(0))
       # d(hf) rows go back to their positions; unmasked rows keep the zero

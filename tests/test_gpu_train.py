@@ -117,6 +117,13 @@ def test_gelu_transpose_colsum_embed(ops):
     assert torch.equal(ops.transpose_bf16(xv[:, :C]).cpu(), xv[:, :C].t().contiguous().cpu()), (R, C)
   xb = _bf(torch.randn(3, 72, 200)).cuda()
   assert torch.equal(ops.transpose_bf16(xb).cpu(), xb.transpose(1, 2).contiguous().cpu())
+  # column sums (bias gradient) riding on the transpose
+  xv = _bf(torch.randn(1000, 776)).cuda()
+  part = torch.full((16, 776), 7.0, device='cuda')
+  xt_ = ops.transpose_bf16(xv, colsum_partial=part)
+  assert torch.equal(xt_.cpu(), xv.t().contiguous().cpu())
+  cs = ops.colsum_reduce(part, torch.empty(776, device='cuda'), 776, 16, 1)
+  assert _rel(cs, xv.float().sum(0)) < 1e-5
   # column sums
   z = _bf(torch.randn(1000, 770))
   assert _rel(ops.colsum_bf16(z.cuda()), z.float().sum(0)) < 1e-5
@@ -241,13 +248,13 @@ def test_adamw_ema_clip(ops):
 V_T, MASK_T = 300, 103     # mask id inside the vocabulary, like bert-base-uncased (LM1B)
 
 
-def _make_trainer(p_drop, time_conditioning=False, seed=5):
+def _make_trainer(p_drop, time_conditioning=False, seed=5, extra=()):
   from mdlm_amd.config import load_config
   from mdlm_amd.diffusion import Diffusion
   from mdlm_amd.tokenizer import SyntheticTokenizer
   from mdlm_amd.train import Trainer
   cfg = load_config(['model=tiny', 'loader.eval_batch_size=4',
-                     f'time_conditioning={time_conditioning}'])
+                     f'time_conditioning={time_conditioning}', *extra])
   tok = SyntheticTokenizer(vocab_size=V_T, eos_token_id=7, mask_token_id=MASK_T)
   model = Diffusion(cfg, tok).cuda()
   assert model.mask_index == MASK_T and model.vocab_size == V_T
@@ -464,3 +471,51 @@ def test_ddp_two_ranks_match_accumulation(ops, tmp_path):
   assert (g_ref - g_ddp).norm() < 1e-5 * g_ref.norm()
   diff = (tr.P.cpu() - r0['P']).abs()
   assert (diff > 2e-5).float().mean().item() < 1e-3, diff.max().item()
+
+
+@pytest.mark.parametrize('T,N,K,splits', [(1024, 256, 512, 3), (4096, 768, 768, None),
+                                          (64, 256, 256, 1), (2048, 512, 256, 7)])
+def test_gemm_tn_splitk(ops, T, N, K, splits):
+  """Weight + bias gradient straight from token-major dY (T, N) and X (T, K):
+  transposing LDS reads, uneven token ranges, padded leading dimensions."""
+  g = torch.Generator().manual_seed(T + N + K)
+  dY = (torch.randn(T, N + 64, generator=g) * 0.5).to(torch.bfloat16)
+  X = (torch.randn(T, K + 8, generator=g) * 0.5).to(torch.bfloat16)
+  ref = dY[:, :N].double().T @ X[:, :K].double()
+  ref_b = dY[:, :N].double().sum(0)
+  s = ops.tn_splitk_plan(N, K, T) if splits is None else splits
+  part = torch.empty(s * N * K, dtype=torch.float32, device='cuda')
+  bpart = torch.empty(s * N, dtype=torch.float32, device='cuda')
+  out = torch.empty(N, K, dtype=torch.float32, device='cuda')
+  bias = torch.empty(N, dtype=torch.float32, device='cuda')
+  dYc, Xc = dY.cuda()[:, :N], X.cuda()[:, :K]
+  ops.gemm_tn_splitk(dYc, Xc, out, part, bias_out=bias, bias_partials=bpart, splits=splits)
+  err = (out.cpu().double() - ref).abs().max().item()
+  assert err < 2e-4 * T ** 0.5, err
+  assert (bias.cpu().double() - ref_b).abs().max().item() < 1e-4 * T ** 0.5
+  out2 = torch.empty_like(out)
+  ops.gemm_tn_splitk(dYc, Xc, out2, part, splits=splits)   # no bias; bit-reproducible
+  assert torch.equal(out, out2)
+
+
+def test_training_gradients_token_major_path(ops):
+  """hidden 256: every weight-gradient shape tiles by 256, so the Trainer takes
+  the token-major GEMM (no transposed copies) for all Linears and the output layer."""
+  model, cfg, p, tr = _make_trainer(0.0, extra=('model.hidden_size=256', 'model.n_heads=4'))
+  m = cfg.model
+  B, L = 4, m.length
+  x0, attn, t, u = _batch(B, L, seed=31)
+  calls = []
+  orig = ops.gemm_tn_splitk
+  ops.gemm_tn_splitk = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+  try:
+    loss, nlls = tr.forward_backward(x0.cuda(), attn.cuda(), t=t.cuda(), u_xt=u.cuda())
+  finally:
+    ops.gemm_tn_splitk = orig
+  assert len(calls) == 4 * m.n_blocks + 1
+  ref_loss, ref_nlls, ref_g = orc.loss_and_grads(p, x0, attn, t, u, m.n_heads, m.n_blocks,
+                                                 MASK_T, None, 0.0)
+  assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item())
+  g = tr.grads()
+  worst = max((_rel(g[k], ref_g[k]), k) for k in ref_g)
+  assert worst[0] < 6e-2, worst
