@@ -13,10 +13,13 @@
 // Two kernels, no atomics (bitwise reproducible): one workgroup per 64-key
 // block accumulates dK/dV over the query blocks, one per 64-query block
 // accumulates dQ over the key blocks; P and dS are recomputed from the saved
-// lse.  Every matmul is v_mfma_f32_32x32x16_bf16 on 64x64 bf16 tiles staged in
-// LDS with both operands K-contiguous (a transposed copy is written at staging
-// time where the contraction runs over the tile's row index); P / dS go
-// through LDS once as bf16.  Four waves, one 32x32 output tile each.
+// lse.  Every matmul is v_mfma_f32_32x32x16_bf16 on 64x64 bf16 tiles staged
+// row-major in LDS as they lie in HBM; an operand whose contraction index is
+// the tile's ROW index (Q^T, dO^T, K^T, and V, which arrives as v^T) is
+// gathered with the transposing LDS read ds_read_b64_tr_b16 instead of being
+// staged a second time transposed (the scalar transposed stores of the first
+// version were 16-way bank-conflicted).  P / dS go through LDS once as bf16.
+// Four waves, one 32x32 output tile each.
 #include "common.h"
 
 namespace mdlm {
@@ -28,34 +31,49 @@ constexpr int BT = 64;            // tile edge
 constexpr int LDP = 72;           // LDS row stride in elements (144 B: 16-byte aligned, de-phased banks)
 constexpr int TILE_E = BT * LDP;  // elements per LDS tile
 
-// stage a 64x64 bf16 tile (row stride ld elements) into LDS row-major (dst)
-// and / or transposed (dst_t[col][row]); 256 threads
+// stage a 64x64 bf16 tile (row stride ld elements) into LDS row-major; 256 threads
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int64_t ld,
-                                           bf16_t* dst, bf16_t* dst_t, int tid) {
+                                           bf16_t* dst, int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int id = tid + i * 256;
     const int row = id >> 3, ch = id & 7;
-    const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)row * ld + ch * 8);
-    if (dst) *reinterpret_cast<uint4*>(dst + row * LDP + ch * 8) = v;
-    if (dst_t) {
-      const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        dst_t[(ch * 8 + 2 * k) * LDP + row] = (bf16_t)(w[k] & 0xffffu);
-        dst_t[(ch * 8 + 2 * k + 1) * LDP + row] = (bf16_t)(w[k] >> 16);
-      }
-    }
+    *reinterpret_cast<uint4*>(dst + row * LDP + ch * 8) =
+      *reinterpret_cast<const uint4*>(src + (int64_t)row * ld + ch * 8);
   }
 }
 
-// acc[i][j] += sum_k A[i][k] * B[j][k], 32x32 tile, k < 64; A, B point at the
-// tile's first row in LDS.  acc[e]: i = 8*(e>>2) + 4*hh + (e&3), j = r.
-__device__ __forceinline__ void mma64(f32x16& acc, const bf16_t* A, const bf16_t* B, int r, int hh) {
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// Operand fragment of v_mfma_f32_32x32x16_bf16 (lane: row r = lane & 31, k half
+// hh = lane >> 5 -> contraction elements ks*16 + hh*8 .. +7):
+//   frag_row: the tile holds [row][contraction]  (one 16-byte read)
+//   frag_tr : the tile holds [contraction][row]  (two transposing reads; the
+//             16-lane group (lane >> 4) covers rows 16*(group & 1) .. +15, lane
+//             4q+p of it supplies the address of contraction row q, columns 4p..4p+3)
+__device__ __forceinline__ bf16x8 frag_row(const bf16_t* T, int row0, int ks, int r, int hh) {
+  return *reinterpret_cast<const bf16x8*>(T + (row0 + r) * LDP + ks * 16 + hh * 8);
+}
+__device__ __forceinline__ bf16x8 frag_tr(const bf16_t* T, int row0, int ks, int lane) {
+  const int hh = lane >> 5, half = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+  const bf16_t* a = T + (ks * 16 + hh * 8 + q) * LDP + row0 + half * 16 + p * 4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 4 * LDP));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// acc[i][j] += sum_k A[i][k] * B[j][k], 32x32 tile, k < 64.  TA / TB: the operand's
+// tile is stored [contraction][row] and read transposed; a0 / b0 = first row of
+// the 32-row operand block.  acc[e]: i = 8*(e>>2) + 4*hh + (e&3), j = r.
+template <bool TA, bool TB>
+__device__ __forceinline__ void mma64(f32x16& acc, const bf16_t* A, int a0, const bf16_t* B, int b0, int lane) {
+  const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + r * LDP + ks * 16 + hh * 8);
-    const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + r * LDP + ks * 16 + hh * 8);
+    const bf16x8 a = TA ? frag_tr(A, a0, ks, lane) : frag_row(A, a0, ks, r, hh);
+    const bf16x8 b = TB ? frag_tr(B, b0, ks, lane) : frag_row(B, b0, ks, r, hh);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
   }
 }
@@ -94,11 +112,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int H, int L) {
   __shared__ __attribute__((aligned(16))) bf16_t sm[6 * TILE_E];
   bf16_t* Ks = sm;                 // [key][d]
-  bf16_t* Vs = sm + TILE_E;        // [key][d]
-  bf16_t* Qs = sm + 2 * TILE_E;    // [q][d], then P^T [key][q]
-  bf16_t* dOs = sm + 3 * TILE_E;   // [q][d], then dS^T [key][q]
-  bf16_t* QTs = sm + 4 * TILE_E;   // [d][q]
-  bf16_t* dOTs = sm + 5 * TILE_E;  // [d][q]
+  bf16_t* VTs = sm + TILE_E;       // [d][key]  (v^T as stored)
+  bf16_t* Qs = sm + 2 * TILE_E;    // [q][d]
+  bf16_t* dOs = sm + 3 * TILE_E;   // [q][d]
+  bf16_t* PTs = sm + 4 * TILE_E;   // P^T  [key][q]
+  bf16_t* dSTs = sm + 5 * TILE_E;  // dS^T [key][q]
   const int kblocks = L / BT;
   const int kb = blockIdx.x % kblocks;
   const int bh = blockIdx.x / kblocks;
@@ -108,34 +126,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
   const int wa = wid >> 1, wb = wid & 1;  // tile row (key) / tile column (q or d)
   const int key0 = kb * BT;
   const int64_t D = (int64_t)H * 64;
-  stage_tile(k + ((int64_t)bh * L + key0) * 64, 64, Ks, nullptr, tid);
-  stage_tile(vt + (int64_t)bh * 64 * L + key0, L, nullptr, Vs, tid);
+  stage_tile(k + ((int64_t)bh * L + key0) * 64, 64, Ks, tid);
+  stage_tile(vt + (int64_t)bh * 64 * L + key0, L, VTs, tid);
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 dk_acc = zero16, dv_acc = zero16;
   const float sc = 0.125f * 1.4426950408889634f;
   for (int qb = 0; qb < L / BT; ++qb) {
     const int q0 = qb * BT;
-    stage_tile(q + ((int64_t)bh * L + q0) * 64, 64, Qs, QTs, tid);
-    stage_tile(dout + ((int64_t)seq * L + q0) * D + head * 64, D, dOs, dOTs, tid);
+    stage_tile(q + ((int64_t)bh * L + q0) * 64, 64, Qs, tid);
+    stage_tile(dout + ((int64_t)seq * L + q0) * D + head * 64, D, dOs, tid);
     const float lse_q = lse[(int64_t)bh * L + q0 + wb * 32 + r];
     const float del_q = delta[(int64_t)bh * L + q0 + wb * 32 + r];
     __syncthreads();
     f32x16 st = zero16, dpt = zero16;   // S^T, dP^T tiles [key (rows), q (cols)]
-    mma64(st, Ks + wa * 32 * LDP, Qs + wb * 32 * LDP, r, hh);
-    mma64(dpt, Vs + wa * 32 * LDP, dOs + wb * 32 * LDP, r, hh);
-    __syncthreads();  // every wave is done reading Qs / dOs
+    mma64<false, false>(st, Ks, wa * 32, Qs, wb * 32, lane);
+    mma64<true, false>(dpt, VTs, wa * 32, dOs, wb * 32, lane);   // V[key][d] read out of v^T
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const float p = __builtin_amdgcn_exp2f(st[e] * sc - lse_q);
       const float ds = p * (dpt[e] - del_q);
       const int key = wa * 32 + acc_row(e, hh);
-      Qs[key * LDP + wb * 32 + r] = f32_to_bf16(p);
-      dOs[key * LDP + wb * 32 + r] = f32_to_bf16(ds);
+      PTs[key * LDP + wb * 32 + r] = f32_to_bf16(p);
+      dSTs[key * LDP + wb * 32 + r] = f32_to_bf16(ds);
     }
     __syncthreads();
     // dV[key, d] += P^T[key, :] . dO[:, d];  dK[key, d] += dS^T[key, :] . Q[:, d]
-    mma64(dv_acc, Qs + wa * 32 * LDP, dOTs + wb * 32 * LDP, r, hh);
-    mma64(dk_acc, dOs + wa * 32 * LDP, QTs + wb * 32 * LDP, r, hh);
+    // (dO, Q: contraction over their row index q -> transposing reads)
+    mma64<false, true>(dv_acc, PTs, wa * 32, dOs, wb * 32, lane);
+    mma64<false, true>(dk_acc, dSTs, wa * 32, Qs, wb * 32, lane);
     __syncthreads();
   }
   bf16_t* dkp = dk + ((int64_t)bh * L + key0 + wa * 32) * 64 + wb * 32 + r;
@@ -152,14 +170,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ vt,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
     bf16_t* __restrict__ dq, int H, int L) {
-  __shared__ __attribute__((aligned(16))) bf16_t sm[6 * TILE_E];
+  __shared__ __attribute__((aligned(16))) bf16_t sm[5 * TILE_E];
   __shared__ float lse_s[BT], del_s[BT];
   bf16_t* Qs = sm;                // [q][d]
   bf16_t* dOs = sm + TILE_E;      // [q][d]
   bf16_t* Ks = sm + 2 * TILE_E;   // [key][d]
-  bf16_t* Vs = sm + 3 * TILE_E;   // [key][d]
-  bf16_t* KTs = sm + 4 * TILE_E;  // [d][key]
-  bf16_t* dSs = sm + 5 * TILE_E;  // [q][key]
+  bf16_t* VTs = sm + 3 * TILE_E;  // [d][key]  (v^T as stored)
+  bf16_t* dSs = sm + 4 * TILE_E;  // [q][key]
   const int qblocks = L / BT;
   const int qb = blockIdx.x % qblocks;
   const int bh = blockIdx.x / qblocks;
@@ -169,8 +186,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
   const int wa = wid >> 1, wb = wid & 1;  // tile row (q) / tile column (key or d)
   const int q0 = qb * BT;
   const int64_t D = (int64_t)H * 64;
-  stage_tile(q + ((int64_t)bh * L + q0) * 64, 64, Qs, nullptr, tid);
-  stage_tile(dout + ((int64_t)seq * L + q0) * D + head * 64, D, dOs, nullptr, tid);
+  stage_tile(q + ((int64_t)bh * L + q0) * 64, 64, Qs, tid);
+  stage_tile(dout + ((int64_t)seq * L + q0) * D + head * 64, D, dOs, tid);
   if (tid < BT) {
     lse_s[tid] = lse[(int64_t)bh * L + q0 + tid];
     del_s[tid] = delta[(int64_t)bh * L + q0 + tid];
@@ -180,12 +197,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
   const float sc = 0.125f * 1.4426950408889634f;
   for (int kb = 0; kb < L / BT; ++kb) {
     const int key0 = kb * BT;
-    stage_tile(k + ((int64_t)bh * L + key0) * 64, 64, Ks, KTs, tid);
-    stage_tile(vt + (int64_t)bh * 64 * L + key0, L, nullptr, Vs, tid);
+    stage_tile(k + ((int64_t)bh * L + key0) * 64, 64, Ks, tid);
+    stage_tile(vt + (int64_t)bh * 64 * L + key0, L, VTs, tid);
     __syncthreads();
     f32x16 s = zero16, dp = zero16;   // S, dP tiles [q (rows), key (cols)]
-    mma64(s, Qs + wa * 32 * LDP, Ks + wb * 32 * LDP, r, hh);
-    mma64(dp, dOs + wa * 32 * LDP, Vs + wb * 32 * LDP, r, hh);
+    mma64<false, false>(s, Qs, wa * 32, Ks, wb * 32, lane);
+    mma64<false, true>(dp, dOs, wa * 32, VTs, wb * 32, lane);   // V[key][d] read out of v^T
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int qi = wa * 32 + acc_row(e, hh);
@@ -193,8 +210,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
       dSs[qi * LDP + wb * 32 + r] = f32_to_bf16(p * (dp[e] - del_s[qi]));
     }
     __syncthreads();
-    // dQ[q, d] += dS[q, :] . K[:, d]
-    mma64(dq_acc, dSs + wa * 32 * LDP, KTs + wb * 32 * LDP, r, hh);
+    // dQ[q, d] += dS[q, :] . K[:, d]  (K: contraction over its row index key)
+    mma64<false, true>(dq_acc, dSs, wa * 32, Ks, wb * 32, lane);
     __syncthreads();
   }
   bf16_t* dqp = dq + ((int64_t)bh * L + q0 + wa * 32) * 64 + wb * 32 + r;

@@ -22,6 +22,7 @@
 // 16x16x32 issued as X_frag x dY_frag: a lane then holds 4 consecutive k of one
 // n and stores them as one float4.
 #include "common.h"
+#include <type_traits>
 
 namespace mdlm {
 
@@ -49,12 +50,23 @@ constexpr int TN_SLAB = 64;                 // tokens per slab
 constexpr int TN_OP_BYTES = TN_SLAB * 512;  // one operand slab: 64 rows x 256 columns bf16
 constexpr int TN_STAGE = 2 * TN_OP_BYTES;   // dY slab + X slab
 
-__device__ __forceinline__ bf16x8 tr_frag(const char* p) {
-  // tokens 8g .. 8g+3 and 8g+4 .. 8g+7 of this lane's column (two 4-row blocks)
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-    (__attribute__((address_space(3))) s16x4*)(p));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-    (__attribute__((address_space(3))) s16x4*)(p + 4 * 512));
+// One fragment = two transposing reads (tokens 8g..8g+3 and 8g+4..8g+7 of this
+// lane's column).  Issued as inline asm: through the builtin hipcc treats the
+// read as possibly aliasing the LDS-DMA in flight and puts s_waitcnt vmcnt(0) in
+// front of it, which serialises the next slab's DMA with this slab's MFMAs.
+// The asm reads are invisible to the compiler's waitcnt pass, so the kernel
+// waits on lgkmcnt itself (tr_wait) before the MFMAs that consume them; LDS
+// reads return in order, so "at most N outstanding" means all but the last N.
+#define TR_READ(dst, addr, off) \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+template <int OFF>
+__device__ __forceinline__ void tr_frag_issue(s16x4& lo, s16x4& hi, unsigned addr) {
+  TR_READ(lo, addr, OFF);
+  TR_READ(hi, addr, OFF + 4 * 512);
+}
+
+__device__ __forceinline__ bf16x8 frag_join(s16x4 lo, s16x4 hi) {
   const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
@@ -110,6 +122,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_splitk_kernel(TnArgs g) {
   for (int n = 0; n < 4; ++n)
     xbase[n] = TN_OP_BYTES + (8 * gq + q) * 512 + (((wc * 4 + n) ^ fx) * 32) + p * 8;
 
+  // LDS byte offset of smem (the asm reads take raw LDS addresses)
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   int j = blockIdx.x >> 3;
   if (s_begin + j >= s_end) return;
   auto decode = [&](int s, int& tn, int& tk, int& sp) {
@@ -143,40 +157,67 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_splitk_kernel(TnArgs g) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) bsum[m] = 0.f;
 
-    for (int sl = 0; sl < n_slabs; ++sl) {
-      if (sl + 1 < n_slabs) {
-        stage(buf ^ 1, sl + 1);
-      } else if (has_next) {
-        set_src(tn2, tk2, sp2);
-        stage(buf ^ 1, 0);
-      }
-      const char* sb = smem + buf * TN_STAGE;
+    auto slab_loop = [&](auto with_bias) {
+      constexpr bool BIAS = decltype(with_bias)::value;
+      for (int sl = 0; sl < n_slabs; ++sl) {
+        if (sl + 1 < n_slabs) {
+          stage(buf ^ 1, sl + 1);
+        } else if (has_next) {
+          set_src(tn2, tk2, sp2);
+          stage(buf ^ 1, 0);
+        }
+        const unsigned sb = lds0 + buf * TN_STAGE;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 yf[8], xf[4];
+        for (int ks = 0; ks < 2; ++ks) {
+          s16x4 xl[4], xh[4], yl[8], yh[8];
+          // group A: the X fragments and dY fragments 0..3 (16 reads), group B: dY 4..7 (8 reads)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) xf[n] = tr_frag(sb + xbase[n] + ks * 32 * 512);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) yf[m] = tr_frag(sb + ybase[m] + ks * 32 * 512);
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[n], yf[m], acc[m][n], 0, 0, 0);
-        if (do_bias) {
+          for (int n = 0; n < 4; ++n) {
+            if (ks == 0) tr_frag_issue<0>(xl[n], xh[n], sb + xbase[n]);
+            else tr_frag_issue<32 * 512>(xl[n], xh[n], sb + xbase[n]);
+          }
 #pragma unroll
           for (int m = 0; m < 8; ++m) {
-            const s16x8 v = __builtin_bit_cast(s16x8, yf[m]);
-            float t = 0.f;
+            if (ks == 0) tr_frag_issue<0>(yl[m], yh[m], sb + ybase[m]);
+            else tr_frag_issue<32 * 512>(yl[m], yh[m], sb + ybase[m]);
+          }
+          asm volatile("s_waitcnt lgkmcnt(8)"
+                       : "+v"(xl[0]), "+v"(xh[0]), "+v"(xl[1]), "+v"(xh[1]), "+v"(xl[2]), "+v"(xh[2]),
+                         "+v"(xl[3]), "+v"(xh[3]), "+v"(yl[0]), "+v"(yh[0]), "+v"(yl[1]), "+v"(yh[1]),
+                         "+v"(yl[2]), "+v"(yh[2]), "+v"(yl[3]), "+v"(yh[3]));
+          bf16x8 xf[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t += __uint_as_float((unsigned)(unsigned short)v[e] << 16);
-            bsum[m] += t;
+          for (int n = 0; n < 4; ++n) xf[n] = frag_join(xl[n], xh[n]);
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            if (m == 4) {
+              // the MFMAs of m = 0..3 stay in front of this wait (they cover group B's latency)
+              __builtin_amdgcn_sched_barrier(0);
+              asm volatile("s_waitcnt lgkmcnt(0)"
+                           : "+v"(yl[4]), "+v"(yh[4]), "+v"(yl[5]), "+v"(yh[5]), "+v"(yl[6]), "+v"(yh[6]),
+                             "+v"(yl[7]), "+v"(yh[7]));
+            }
+            const bf16x8 yf = frag_join(yl[m], yh[m]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[n], yf, acc[m][n], 0, 0, 0);
+            if constexpr (BIAS) {
+              const s16x8 v = __builtin_bit_cast(s16x8, yf);
+              float t = 0.f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) t += __uint_as_float((unsigned)(unsigned short)v[e] << 16);
+              bsum[m] += t;
+            }
           }
         }
+        // this slab's MFMAs stay in front of the barrier (and of its vmcnt(0)): the
+        // next slab's DMA then has the whole slab's compute to land
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        buf ^= 1;
       }
-      __syncthreads();
-      buf ^= 1;
-    }
+    };
+    if (do_bias) slab_loop(std::true_type{}); else slab_loop(std::false_type{});
 
     // ---- epilogue: acc[m][n][e] = dW[n0 + m*16 + (lane&15)][k0 + n*16 + 4*gq + e]
     float* const plane = g.P + (int64_t)sp * g.N * g.K;
