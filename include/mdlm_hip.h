@@ -283,6 +283,17 @@ int mdlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw
 int mdlm_splitk_reduce(const float* partials, float* out, int64_t n, int splits,
                        int64_t split_stride, void* stream);
 
+/* GELU (dit.py:227, approximate='tanh') fused into the MLP GEMMs of the
+ * training step; C and aux are bf16 (M, N) with leading dimension ldc:
+ *   mode 0: aux = A W^T + bias (the pre-activation autograd saves),
+ *           C   = gelu_tanh(A W^T + bias)               -- forward of mlp.0
+ *   mode 1: C   = bf16(A W^T) * gelu_tanh'(aux)         -- d(pre) from d(act) = dY W2,
+ *           the backward of the GELU applied in the epilogue of the dX GEMM of mlp.2
+ * M % 128 == 0, K % 64 == 0, ldc % 8 == 0. */
+int mdlm_gemm_bf16_gelu(const void* A, int64_t lda, const void* W, const float* bias,
+                        void* C, void* aux, int64_t ldc, int64_t M, int N, int K,
+                        int mode, void* stream);
+
 /* The same weight gradient on TOKEN-MAJOR operands, as the forward / backward
  * kernels leave them (no transposed copies): dY (T, N) ld ldy, X (T, K) ld ldx,
  * both bf16;  partials[s][N][K] = sum over the tokens of range s of

@@ -65,6 +65,7 @@ SIGNATURES = {
   'mdlm_embed_grad': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp],
   'mdlm_subs_nll_bwd': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
   'mdlm_gemm_bf16_splitk': [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _i32, _vp],
+  'mdlm_gemm_bf16_gelu': [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
   'mdlm_gemm_tn_splitk': [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
   'mdlm_splitk_reduce': [_vp, _vp, _i64, _i32, _i64, _vp],
   'mdlm_grad_sumsq': [_vp, _i64, _vp, _vp, _vp],

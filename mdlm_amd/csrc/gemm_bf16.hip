@@ -32,6 +32,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 64;
+constexpr int EPI_BIAS_GELU_SAVE = 4;   // internal: mdlm_gemm_bf16_gelu mode 0
+constexpr int EPI_MUL_GELU_GRAD = 5;    // internal: mdlm_gemm_bf16_gelu mode 1
 
 struct GemmArgs {
   const bf16_t* A; int64_t lda;
@@ -39,6 +41,10 @@ struct GemmArgs {
   // split-K (fp32 EPI_STORE only): split s reduces K columns [s*K, (s+1)*K) of
   // A and W into C + s*c_split_stride (partial sums, added up by a second kernel)
   int splits; int64_t c_split_stride;
+  // training-step GELU fusions (bf16 outputs, same ldc as C):
+  //   EPI_BIAS_GELU_SAVE : aux = second OUTPUT, receives acc + bias (the pre-activation)
+  //   EPI_MUL_GELU_GRAD  : aux = INPUT pre-activation; C = (acc) * gelu'(aux)
+  void* aux;
   const float* bias;
   void* C; int64_t ldc;
   int64_t M; int N; int K;
@@ -77,6 +83,15 @@ __device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
   const f32x2 d = e + one;
   const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
   return x * r;
+}
+
+// d/dx of gelu_tanh: 0.5 (1 + th) + 0.5 x (1 - th^2) sqrt(2/pi) (1 + 3*0.044715 x^2),
+// th = tanh(y) = 1 - 2 / (1 + exp(2y))
+__device__ __forceinline__ float gelu_tanh_grad_fast(float x) {
+  const float x2 = x * x;
+  const float y2l = 2.3022082f * x * (1.f + 0.044715f * x2);   // 2y * log2(e)
+  const float th = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(y2l));
+  return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * (0.7978845608f * (1.f + 0.134145f * x2));
 }
 
 __device__ __forceinline__ float bf16_round(float x) { return bf16_to_f32(f32_to_bf16(x)); }
@@ -244,6 +259,36 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
 #pragma unroll
           for (int it = 0; it < MS * 2; ++it) drs[it] = orow0 + it * 8 + (lane >> 3);
         }
+        if constexpr (EPI == EPI_BIAS_GELU_SAVE) {
+          // first pass through the LDS tile: the pre-activation acc + bias -> aux
+          // (one wave's LDS accesses execute in order: no barrier between the passes)
+          TC* const Ap0 = reinterpret_cast<TC*>(g.aux) + gcol0;
+#pragma unroll
+          for (int m = 0; m < MS; ++m) {
+            const int row = m * 16 + fr;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+              const int c16 = n * 2 + (fq >> 1);
+              *reinterpret_cast<uint2*>(ep + row * 128 + ((c16 ^ (row & 7)) * 16) + (fq & 1) * 8) =
+                make_uint2(pack_bf16x2(acc(m, n)[0] + ec.bias4[n].x, acc(m, n)[1] + ec.bias4[n].y),
+                           pack_bf16x2(acc(m, n)[2] + ec.bias4[n].z, acc(m, n)[3] + ec.bias4[n].w));
+            }
+          }
+#pragma unroll
+          for (int it = 0; it < MS * 2; ++it) {
+            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((ch ^ (row & 7)) * 16));
+            store16<true>(Ap0 + drs[it] * g.ldc + ch * 8, v, g.dbg);
+          }
+        }
+        // pre-activation rows of the GELU-gradient epilogue, all loads in flight
+        uint4 pre[MS * 2];
+        if constexpr (EPI == EPI_MUL_GELU_GRAD) {
+          const TC* const Ap0 = reinterpret_cast<const TC*>(g.aux) + gcol0;
+#pragma unroll
+          for (int it = 0; it < MS * 2; ++it)
+            pre[it] = *reinterpret_cast<const uint4*>(Ap0 + drs[it] * g.ldc + (lane & 7) * 8);
+        }
         // registers -> (bias, GELU) -> packed bf16 -> swizzled LDS tile [MS*16][64]
 #pragma unroll
         for (int m = 0; m < MS; ++m) {
@@ -252,7 +297,7 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
           for (int n = 0; n < 4; ++n) {
             f32x2 lo = {acc(m, n)[0] + ec.bias4[n].x, acc(m, n)[1] + ec.bias4[n].y};
             f32x2 hi = {acc(m, n)[2] + ec.bias4[n].z, acc(m, n)[3] + ec.bias4[n].w};
-            if constexpr (EPI == MDLM_EPI_BIAS_GELU) { lo = gelu_tanh2(lo); hi = gelu_tanh2(hi); }
+            if constexpr (EPI == MDLM_EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) { lo = gelu_tanh2(lo); hi = gelu_tanh2(hi); }
             const int c16 = n * 2 + (fq >> 1);
             *reinterpret_cast<uint2*>(ep + row * 128 + ((c16 ^ (row & 7)) * 16) + (fq & 1) * 8) =
               make_uint2(pack_bf16x2(lo.x, lo.y), pack_bf16x2(hi.x, hi.y));
@@ -261,7 +306,21 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
 #pragma unroll
         for (int it = 0; it < MS * 2; ++it) {
           const int row = it * 8 + (lane >> 3), ch = lane & 7;
-          const uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((ch ^ (row & 7)) * 16));
+          uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((ch ^ (row & 7)) * 16));
+          if constexpr (EPI == EPI_MUL_GELU_GRAD) {
+            // the bf16-rounded dX times gelu'(pre): the arithmetic of the separate
+            // GELU-backward pass (train_ops.hip), without its HBM round trip
+            const unsigned dv[4] = {v.x, v.y, v.z, v.w};
+            const unsigned pv[4] = {pre[it].x, pre[it].y, pre[it].z, pre[it].w};
+            unsigned o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float d0 = __uint_as_float(dv[k] << 16) * gelu_tanh_grad_fast(__uint_as_float(pv[k] << 16));
+              const float d1 = __uint_as_float(dv[k] & 0xffff0000u) * gelu_tanh_grad_fast(__uint_as_float(pv[k] & 0xffff0000u));
+              o[k] = pack_bf16x2(d0, d1);
+            }
+            v = make_uint4(o[0], o[1], o[2], o[3]);
+          }
           const int64_t dr = drs[it];
           if (dr >= 0) store16<true>(Cp0 + dr * g.ldc + ch * 8, v, g.dbg);
         }
@@ -320,6 +379,12 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
             const int cc = n * 16 + fq * 4 + jj;
             if (gcol0 + cc < g.N) {
               float o = acc(m, n)[jj] + (g.bias ? g.bias[gcol0 + cc] : 0.f);
+              if constexpr (EPI == EPI_BIAS_GELU_SAVE) {
+                elem<TC>::store(reinterpret_cast<TC*>(g.aux) + gcol0 + dr * g.ldc + cc, o);
+                o = gelu_tanh(o);
+              }
+              if constexpr (EPI == EPI_MUL_GELU_GRAD)
+                o = bf16_round(o) * gelu_tanh_grad_fast(elem<TC>::load(reinterpret_cast<const TC*>(g.aux) + gcol0 + dr * g.ldc + cc));
               if constexpr (EPI == MDLM_EPI_BIAS_GELU) o = gelu_tanh(o);
               if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL)
                 o = g.residual[(grow0 + row) * g.ldc + gcol0 + cc] + gate_row[gcol0 + cc] * o;
@@ -660,7 +725,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
   g.mod_ld = mod_ld; g.out_sample_map = out_sample_map; g.out_row_map = out_row_map;
   g.rot_cos = rot_cos; g.rot_sin = rot_sin; g.n_heads = n_heads; g.m_rows_dev = m_rows_dev;
   g.tiles_m = 0; g.tiles_n = 0; g.dbg = g_dbg;
-  g.ldw = K; g.splits = 1; g.c_split_stride = 0;
+  g.ldw = K; g.splits = 1; g.c_split_stride = 0; g.aux = nullptr;
   hipStream_t s = (hipStream_t)stream;
   // 16-byte row stores: 8 bf16 or 4 fp32 per lane
   const int64_t per16 = dtype_c == MDLM_F32 ? 4 : 8;
@@ -736,7 +801,7 @@ extern "C" int mdlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
   g.gate = nullptr; g.residual = nullptr; g.rows_per_mod = 1; g.n_mod = 1; g.mod_ld = 0;
   g.out_sample_map = nullptr; g.out_row_map = nullptr; g.rot_cos = nullptr; g.rot_sin = nullptr;
   g.n_heads = 0; g.m_rows_dev = nullptr; g.tiles_m = 0; g.tiles_n = 0; g.dbg = 0;
-  g.splits = splits; g.c_split_stride = M * (int64_t)N; g.vec_ok = 1;
+  g.splits = splits; g.c_split_stride = M * (int64_t)N; g.vec_ok = 1; g.aux = nullptr;
   return launch_gemm<MDLM_EPI_STORE, float>(g, (hipStream_t)stream);
 }
 
@@ -752,4 +817,29 @@ extern "C" int mdlm_splitk_reduce(const float* partials, float* out, int64_t n, 
     (const float4*)partials, (float4*)out, n4, splits, split_stride / 4);
   MDLM_LAUNCH_CHECK();
   return 0;
+}
+
+
+// ---- GELU fused into the MLP GEMMs of the training step ----------------------
+extern "C" int mdlm_gemm_bf16_gelu(const void* A, int64_t lda, const void* W, const float* bias,
+                                   void* C, void* aux, int64_t ldc, int64_t M, int N, int K,
+                                   int mode, void* stream) {
+  if (M == 0) return 0;
+  MDLM_CHECK_ARG(A && W && C && aux, "gemm_bf16_gelu: null pointer");
+  MDLM_CHECK_ARG(mode == 0 || mode == 1, "gemm_bf16_gelu: mode must be 0 (save) or 1 (gradient)");
+  MDLM_CHECK_ARG(M > 0 && N > 0 && K > 0 && M % 128 == 0 && K % BK == 0, "gemm_bf16_gelu: M %% 128, K %% 64");
+  MDLM_CHECK_ARG(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0 &&
+                 (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)aux) & 15) == 0,
+                 "gemm_bf16_gelu: 16-byte aligned operands, leading dimensions %% 8 == 0");
+  MDLM_CHECK_ARG(!bias || ((uintptr_t)bias & 15) == 0, "gemm_bf16_gelu: bias must be 16-byte aligned");
+  MDLM_CHECK_ARG(M * (int64_t)(N > K ? N : K) < (1ll << 40), "gemm_bf16_gelu: too large");
+  GemmArgs g;
+  g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = K; g.bias = bias;
+  g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.gate = nullptr; g.residual = nullptr;
+  g.rows_per_mod = 1; g.n_mod = 1; g.mod_ld = 0; g.out_sample_map = nullptr; g.out_row_map = nullptr;
+  g.rot_cos = nullptr; g.rot_sin = nullptr; g.n_heads = 0; g.m_rows_dev = nullptr;
+  g.tiles_m = 0; g.tiles_n = 0; g.dbg = 0; g.splits = 1; g.c_split_stride = 0; g.vec_ok = 1;
+  g.aux = aux;
+  if (mode == 0) return launch_gemm<EPI_BIAS_GELU_SAVE, bf16_t>(g, (hipStream_t)stream);
+  return launch_gemm<EPI_MUL_GELU_GRAD, bf16_t>(g, (hipStream_t)stream);
 }

@@ -383,6 +383,19 @@ def gemm_bf16_splitk(A, W, out, partials, splits=None):
   return out
 
 
+def gemm_bf16_gelu(A, W, C, aux, bias=None, grad=False):
+  """grad=False: aux <- A W^T + bias, C <- gelu_tanh(aux)   (mlp.0 forward, both saved)
+  grad=True : C <- bf16(A W^T) * gelu_tanh'(aux)          (d(pre) in the dX GEMM of mlp.2)"""
+  M, K = A.shape
+  N = W.shape[0]
+  assert A.dtype == W.dtype == C.dtype == aux.dtype == torch.bfloat16
+  assert W.shape[1] == K and W.is_contiguous() and A.stride(1) == 1
+  assert C.shape == aux.shape == (M, N) and C.stride(0) == aux.stride(0) and C.stride(1) == 1
+  call('mdlm_gemm_bf16_gelu', A.data_ptr(), A.stride(0), W.data_ptr(), _p(bias),
+       C.data_ptr(), aux.data_ptr(), C.stride(0), int(M), N, K, int(bool(grad)), _stream())
+  return C
+
+
 def tn_splitk_plan(N, K, T, max_splits=64, min_slabs=16):
   """Token ranges for mdlm_gemm_tn_splitk: fills the 256 persistent workgroups
   evenly (tiles * splits close below a multiple of 256) while a range keeps

@@ -335,9 +335,9 @@ class Trainer:
                                     ld6, p, seed, a['drop'][0])
       ops.ln_modulate(a['x_mid'], self._p32(pre_ + 'norm2.weight'), mod[:, 3 * D:4 * D],
                       mod[:, 4 * D:5 * D], a['h2'], L, n_mod, ld6)
-      ops.gemm_bf16(a['h2'], self._w16(pre_ + 'mlp.0.weight'), a['pre'], EPI_STORE,
-                    bias=self._p32(pre_ + 'mlp.0.bias'))
-      ops.gelu_fwd(a['pre'], a['act'])
+      # mlp.0 + GELU in one GEMM: the epilogue writes the pre-activation and the activation
+      ops.gemm_bf16_gelu(a['h2'], self._w16(pre_ + 'mlp.0.weight'), a['act'], a['pre'],
+                         bias=self._p32(pre_ + 'mlp.0.bias'))
       ops.gemm_bf16(a['act'], self._w16(pre_ + 'mlp.2.weight'), a['y2'], EPI_STORE,
                     bias=self._p32(pre_ + 'mlp.2.bias'))
       a['drop'][1] = model._draw(M * D // 4)[1]
@@ -408,8 +408,10 @@ class Trainer:
                                     L, n_mod, ld6, p, seed, a['drop'][1])
       ops.colsum_reduce(ws['part1'], red1, D, (M // 32) // n_mod, n_mod)
       dm[:, 5 * D:] = red1
-      self._linear_bwd(ws['d_md'], a['act'], pre_ + 'mlp.2.weight', pre_ + 'mlp.2.bias', ws, ws['d_m4'])
-      ops.gelu_bwd(ws['d_m4'], a['pre'], ws['d_m4b'])
+      # dW2 / db2, then d(pre) = (dY W2) * gelu'(pre) straight out of the dX GEMM
+      self._linear_bwd(ws['d_md'], a['act'], pre_ + 'mlp.2.weight', pre_ + 'mlp.2.bias', ws, None)
+      ops.gemm_bf16_gelu(ws['d_md'], self._wt(pre_ + 'mlp.2.weight', ws), ws['d_m4b'], a['pre'],
+                         grad=True)
       self._linear_bwd(ws['d_m4b'], a['h2'], pre_ + 'mlp.0.weight', pre_ + 'mlp.0.bias', ws, ws['d_md'])
       ops.ln_modulate_bwd(ws['d_md'], a['x_mid'], self._p32(pre_ + 'norm2.weight'),
                           mod[:, 4 * D:5 * D], dx, ws['part3'], L, n_mod, ld6, accumulate=True)

@@ -519,3 +519,32 @@ def test_training_gradients_token_major_path(ops):
   g = tr.grads()
   worst = max((_rel(g[k], ref_g[k]), k) for k in ref_g)
   assert worst[0] < 6e-2, worst
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 3072, 768), (384, 520, 128)])
+def test_gemm_gelu_fusions(ops, M, N, K):
+  """mlp.0 forward writing pre-activation + GELU, and the GELU backward in the
+  epilogue of the dX GEMM, against the separate kernels / torch autograd."""
+  g = torch.Generator().manual_seed(N)
+  A = _bf(torch.randn(M, K, generator=g)).cuda()
+  W = _bf(torch.randn(N, K, generator=g) * 0.05).cuda()
+  b = (torch.randn(N, generator=g) * 0.1).cuda()
+  ld = (N + 7) // 8 * 8 + 8
+  pre = torch.zeros(M, ld, dtype=torch.bfloat16, device='cuda')[:, :N]
+  act = torch.zeros(M, ld, dtype=torch.bfloat16, device='cuda')[:, :N]
+  ops.gemm_bf16_gelu(A, W, act, pre, bias=b)
+  ref_pre = A.float() @ W.float().T + b
+  assert _rel(pre.float(), ref_pre) < 1e-2
+  assert _rel(act.float(), F.gelu(ref_pre, approximate='tanh')) < 1e-2
+  # backward: C = bf16(A W^T) * gelu'(aux)
+  x = (pre.float() * 3).requires_grad_(True)
+  F.gelu(x, approximate='tanh').sum().backward()
+  aux = _bf(x.detach())
+  auxp = torch.zeros(M, ld, dtype=torch.bfloat16, device='cuda')[:, :N]
+  auxp.copy_(aux)
+  out = torch.zeros(M, ld, dtype=torch.bfloat16, device='cuda')[:, :N]
+  ops.gemm_bf16_gelu(A, W, out, auxp, grad=True)
+  xg = aux.float().requires_grad_(True)
+  F.gelu(xg, approximate='tanh').sum().backward()
+  ref = _bf(A.float() @ W.float().T).float() * xg.grad
+  assert _rel(out.float(), ref) < 1e-2
