@@ -27,6 +27,8 @@ __device__ __forceinline__ float4 bf16x4_to_f32(uint2 v) {
 // (the residual-stream gradient).  Column partial sums over the 32 rows of the
 // workgroup: [0] dw = dh*n*(1+scale), [1] dscale = dh*n*w, [2] dshift = dh.
 constexpr int LNB_ROWS = 32;
+// NV = float4 columns per lane: 3 for D <= 768 (DiT-small: no idle register sets), else 4
+template <int NV>
 __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(
     const bf16_t* __restrict__ dh, const float* __restrict__ x,
     const float* __restrict__ ln_w, const float* __restrict__ scale,
@@ -39,10 +41,10 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(
   const int64_t mrow = (row0 / rows_per_mod) % n_mod;
   const float4* w4 = reinterpret_cast<const float4*>(ln_w);
   const float4* sc4 = reinterpret_cast<const float4*>(scale + mrow * mod_ld);
-  float4 w[TR_NV], g1[TR_NV], pw[TR_NV], ps[TR_NV], pb[TR_NV];
+  float4 w[NV], g1[NV], pw[NV], ps[NV], pb[NV];
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int i = 0; i < TR_NV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
     w[i] = c < nv ? w4[c] : z4;
     const float4 s = c < nv ? sc4[c] : z4;
@@ -54,19 +56,23 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(
     if (r >= rows) break;
     const float4* xr = reinterpret_cast<const float4*>(x + r * D);
     const uint2* dr = reinterpret_cast<const uint2*>(dh + r * D);
-    float4 v[TR_NV], d[TR_NV];
+    float4 v[NV], d[NV], acc_in[NV];
+    float4* o = reinterpret_cast<float4*>(dx_inout + r * D);
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < TR_NV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
       v[i] = c < nv ? xr[c] : z4;
       d[i] = c < nv ? bf16x4_to_f32(dr[c]) : z4;
+      // the running residual gradient is fetched with the row, not after the
+      // three wave reductions that precede its use
+      acc_in[i] = (accumulate && c < nv) ? o[c] : z4;
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < TR_NV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
         v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
@@ -75,9 +81,9 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
     float s1 = 0.f, s2 = 0.f;
-    float4 dn[TR_NV];
+    float4 dn[NV];
 #pragma unroll
-    for (int i = 0; i < TR_NV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;  // n
       dn[i] = make_float4(d[i].x * w[i].x * g1[i].x, d[i].y * w[i].y * g1[i].y,
                           d[i].z * w[i].z * g1[i].z, d[i].w * w[i].w * g1[i].w);
@@ -91,24 +97,21 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(
     }
     s1 = wave_sum(s1) / (float)D;
     s2 = wave_sum(s2) / (float)D;
-    float4* o = reinterpret_cast<float4*>(dx_inout + r * D);
 #pragma unroll
-    for (int i = 0; i < TR_NV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
         float4 r4 = make_float4(rstd * (dn[i].x - s1 - v[i].x * s2), rstd * (dn[i].y - s1 - v[i].y * s2),
                                 rstd * (dn[i].z - s1 - v[i].z * s2), rstd * (dn[i].w - s1 - v[i].w * s2));
-        if (accumulate) {
-          const float4 a = o[c];
-          r4.x += a.x; r4.y += a.y; r4.z += a.z; r4.w += a.w;
-        }
+        const float4 a = acc_in[i];
+        r4.x += a.x; r4.y += a.y; r4.z += a.z; r4.w += a.w;
         o[c] = r4;
       }
     }
   }
   float4* sm = reinterpret_cast<float4*>(lnb_smem);
 #pragma unroll
-  for (int i = 0; i < TR_NV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
       sm[(wid * 3 + 0) * nv + c] = pw[i];
@@ -616,8 +619,12 @@ extern "C" int mdlm_ln_modulate_bwd(const void* dh_bf16, const float* x, const f
   MDLM_CHECK_ARG((((uintptr_t)dh_bf16 | (uintptr_t)x | (uintptr_t)ln_w | (uintptr_t)scale | (uintptr_t)dx_inout | (uintptr_t)partial) & 15) == 0 && mod_ld % 4 == 0,
                  "ln_modulate_bwd: 16-byte alignment");
   const unsigned blocks = (unsigned)((rows + LNB_ROWS - 1) / LNB_ROWS);
-  ln_modulate_bwd_kernel<<<blocks, 256, 4 * 3 * D * sizeof(float), ST(stream)>>>(
-    (const bf16_t*)dh_bf16, x, ln_w, scale, dx_inout, partial, rows, D, rows_per_mod, n_mod, mod_ld, accumulate);
+  if (D <= 768)
+    ln_modulate_bwd_kernel<3><<<blocks, 256, 4 * 3 * D * sizeof(float), ST(stream)>>>(
+      (const bf16_t*)dh_bf16, x, ln_w, scale, dx_inout, partial, rows, D, rows_per_mod, n_mod, mod_ld, accumulate);
+  else
+    ln_modulate_bwd_kernel<4><<<blocks, 256, 4 * 3 * D * sizeof(float), ST(stream)>>>(
+      (const bf16_t*)dh_bf16, x, ln_w, scale, dx_inout, partial, rows, D, rows_per_mod, n_mod, mod_ld, accumulate);
   MDLM_LAUNCH_CHECK();
   return 0;
 }
