@@ -58,7 +58,7 @@ constexpr int TN_STAGE = 2 * TN_OP_BYTES;   // dY slab + X slab
 // waits on lgkmcnt itself (tr_wait) before the MFMAs that consume them; LDS
 // reads return in order, so "at most N outstanding" means all but the last N.
 #define TR_READ(dst, addr, off) \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 
 template <int OFF>
 __device__ __forceinline__ void tr_frag_issue(s16x4& lo, s16x4& hi, unsigned addr) {
