@@ -208,7 +208,7 @@ def semi_ar_bench(args):
   torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
   t0 = time.perf_counter()
   for _ in range(args.steps):
-    nfe_steps, _, seq_lens = run()
+    nfe_steps, _, _ = run()
   torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
   el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
   n_tok = L + cfg.sampling.num_strides * cfg.sampling.stride_length

@@ -386,7 +386,6 @@ class Trainer:
       # d(hf) rows go back to their positions; unmasked rows keep the zero
       ops.gemm_bf16(dlc, ws['wvT'], ws['d_md'], EPI_STORE, out_row_map=ws['scatter'])
     dx = ws['dx']
-    nb32 = L // 32
     red3 = torch.empty(n_mod, 3, D, device=self.dev)
     red1 = torch.empty(n_mod, D, device=self.dev)
     ops.ln_modulate_bwd(ws['d_md'], ws['x_last'], self._p32('output_layer.norm_final.weight'),
