@@ -548,3 +548,19 @@ def test_gemm_gelu_fusions(ops, M, N, K):
   F.gelu(xg, approximate='tanh').sum().backward()
   ref = _bf(A.float() @ W.float().T).float() * xg.grad
   assert _rel(out.float(), ref) < 1e-2
+
+
+def test_training_step_without_masked_tokens(ops):
+  """q_xt may leave a micro-batch without a single masked position (small t):
+  the loss is 0, every gradient is 0 and the optimizer step is a no-op on the weights."""
+  model, cfg, p, tr = _make_trainer(0.1)
+  B, L = 4, cfg.model.length
+  x0, attn, t, _ = _batch(B, L, seed=41)
+  u = torch.full((B, L), 0.9999)            # u >= move_chance everywhere: nothing is masked
+  loss, nlls = tr.forward_backward(x0.cuda(), attn.cuda(), t=t.cuda() * 0.5, u_xt=u.cuda())
+  assert loss.item() == 0.0 and float(nlls.abs().max()) == 0.0
+  assert float(tr.G.abs().max()) == 0.0
+  before = tr.P.clone()
+  tr.step_count = 5                          # past the warm-up: lr > 0
+  tr.optimizer_step()
+  assert torch.equal(tr.P, before)
