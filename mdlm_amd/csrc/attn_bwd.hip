@@ -219,6 +219,128 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
   for (int e = 0; e < 16; ++e) dqp[acc_row(e, hh) * 64] = f32_to_bf16(dq_acc[e] * 0.125f);
 }
 
+// ---------------------------------------------------------------------------
+// Short sequences (L == 128, the LM1B recipe): ONE workgroup per (sequence,
+// head) holds Q, K, dO, v^T and the whole 128x128 P / dS in LDS (139 KiB), so
+// S and dP are computed once (5 matmuls instead of the 7 of the two-kernel
+// scheme), nothing is staged twice and delta = rowsum(dO * O) is formed in
+// the same kernel.  8 waves: two 32x32 tiles of S / dP each, then one 32x32
+// tile each of dV, dK and dQ.
+constexpr int LQ = 128;
+constexpr int LDW = 136;   // row stride of the 128-wide tiles (272 B: 16-byte aligned, de-phased banks)
+
+template <int LD>
+__device__ __forceinline__ bf16x8 fragr(const bf16_t* T, int row0, int ks, int r, int hh) {
+  return *reinterpret_cast<const bf16x8*>(T + (row0 + r) * LD + ks * 16 + hh * 8);
+}
+template <int LD>
+__device__ __forceinline__ bf16x8 fragt(const bf16_t* T, int col0, int ks, int lane) {
+  const int hh = lane >> 5, half = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+  const bf16_t* a = T + (ks * 16 + hh * 8 + q) * LD + col0 + half * 16 + p * 4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 4 * LD));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+// acc[i][j] += sum_{k < 16*KS} A[i][k] B[j][k]; TA / TB: operand stored [contraction][row]
+template <bool TA, bool TB, int LDA, int LDB, int KS>
+__device__ __forceinline__ void mmak(f32x16& acc, const bf16_t* A, int a0, const bf16_t* B, int b0, int lane) {
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 a, b;
+    if constexpr (TA) a = fragt<LDA>(A, a0, ks, lane); else a = fragr<LDA>(A, a0, ks, r, hh);
+    if constexpr (TB) b = fragt<LDB>(B, b0, ks, lane); else b = fragr<LDB>(B, b0, ks, r, hh);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_l128_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ vt,
+    const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+    bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int H) {
+  extern __shared__ __attribute__((aligned(16))) char l128_smem[];
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(l128_smem);   // [128 q][LDP]
+  bf16_t* Ks = Qs + LQ * LDP;                          // [128 key][LDP]
+  bf16_t* dOs = Ks + LQ * LDP;                         // [128 q][LDP]
+  bf16_t* VTs = dOs + LQ * LDP;                        // [64 d][LDW]   (v^T as stored)
+  bf16_t* Ps = VTs + 64 * LDW;                         // [128 q][LDW]
+  bf16_t* dSs = Ps + LQ * LDW;                         // [128 q][LDW]
+  float* lse_s = reinterpret_cast<float*>(dSs + LQ * LDW);
+  float* del_s = lse_s + LQ;
+  const int bh = blockIdx.x;
+  const int seq = bh / H, head = bh - seq * H;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int64_t D = (int64_t)H * 64;
+  // ---- stage (16-byte chunks): Q, K, dO: 128 rows x 8 chunks; v^T: 64 rows x 16 chunks
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + i * 512;
+    const int row = id >> 3, ch = id & 7;
+    *reinterpret_cast<uint4*>(Qs + row * LDP + ch * 8) =
+      *reinterpret_cast<const uint4*>(q + ((int64_t)bh * LQ + row) * 64 + ch * 8);
+    *reinterpret_cast<uint4*>(Ks + row * LDP + ch * 8) =
+      *reinterpret_cast<const uint4*>(k + ((int64_t)bh * LQ + row) * 64 + ch * 8);
+    *reinterpret_cast<uint4*>(dOs + row * LDP + ch * 8) =
+      *reinterpret_cast<const uint4*>(dout + ((int64_t)seq * LQ + row) * D + head * 64 + ch * 8);
+    const int vrow = id >> 4, vch = id & 15;
+    *reinterpret_cast<uint4*>(VTs + vrow * LDW + vch * 8) =
+      *reinterpret_cast<const uint4*>(vt + ((int64_t)bh * 64 + vrow) * LQ + vch * 8);
+  }
+  // ---- delta[q] = sum_d dO * O (four lanes per row, 16 columns each), lse
+  {
+    const int row = tid >> 2, c0 = (tid & 3) * 16;
+    const int64_t off = ((int64_t)seq * LQ + row) * D + head * 64 + c0;
+    float sacc = 0.f;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const uint4 a = *reinterpret_cast<const uint4*>(o + off + h2 * 8);
+      const uint4 b = *reinterpret_cast<const uint4*>(dout + off + h2 * 8);
+      const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        sacc += __uint_as_float(aw[e] << 16) * __uint_as_float(bw[e] << 16) +
+                __uint_as_float(aw[e] & 0xffff0000u) * __uint_as_float(bw[e] & 0xffff0000u);
+    }
+    sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2);
+    if ((tid & 3) == 0) { del_s[row] = sacc; lse_s[row] = lse[(int64_t)bh * LQ + row]; }
+  }
+  __syncthreads();
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float sc = 0.125f * 1.4426950408889634f;
+  // ---- phase 1: S = Q K^T, dP = dO V^T  ->  P, dS (bf16) for the whole 128 x 128
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    const int t = wid * 2 + t2, ti = t >> 2, tj = t & 3;   // tile (q block, key block)
+    f32x16 s = zero16, dp = zero16;
+    mmak<false, false, LDP, LDP, 4>(s, Qs, ti * 32, Ks, tj * 32, lane);
+    mmak<false, true, LDP, LDW, 4>(dp, dOs, ti * 32, VTs, tj * 32, lane);   // V[key][d] out of v^T
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int qi = ti * 32 + acc_row(e, hh);
+      const float p = __builtin_amdgcn_exp2f(s[e] * sc - lse_s[qi]);
+      Ps[qi * LDW + tj * 32 + r] = f32_to_bf16(p);
+      dSs[qi * LDW + tj * 32 + r] = f32_to_bf16(p * (dp[e] - del_s[qi]));
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: one 32 x 32 tile each of dV, dK (rows = keys) and dQ (rows = queries)
+  const int ta = wid >> 1, tb = wid & 1;
+  f32x16 dv_acc = zero16, dk_acc = zero16, dq_acc = zero16;
+  mmak<true, true, LDW, LDP, 8>(dv_acc, Ps, ta * 32, dOs, tb * 32, lane);    // sum_q P[q][key] dO[q][d]
+  mmak<true, true, LDW, LDP, 8>(dk_acc, dSs, ta * 32, Qs, tb * 32, lane);    // sum_q dS[q][key] Q[q][d]
+  mmak<false, true, LDW, LDP, 8>(dq_acc, dSs, ta * 32, Ks, tb * 32, lane);   // sum_key dS[q][key] K[key][d]
+  const int64_t obase = ((int64_t)bh * LQ + ta * 32) * 64 + tb * 32 + r;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = acc_row(e, hh);
+    dv[obase + row * 64] = f32_to_bf16(dv_acc[e]);
+    dk[obase + row * 64] = f32_to_bf16(dk_acc[e] * 0.125f);
+    dq[obase + row * 64] = f32_to_bf16(dq_acc[e] * 0.125f);
+  }
+}
+
 }  // namespace mdlm
 
 using namespace mdlm;
@@ -236,6 +358,21 @@ extern "C" int mdlm_attn_bwd(const void* q, const void* k, const void* vt, const
   const int64_t blocks = (int64_t)n_seq * H * (L / BT);
   MDLM_CHECK_ARG(blocks < (1ll << 31) && M * H * 8 / 256 < (1ll << 31), "attn_bwd: too many blocks");
   hipStream_t s = (hipStream_t)stream;
+  if (L == LQ) {
+    constexpr int LDS = (3 * LQ * LDP + 64 * LDW + 2 * LQ * LDW) * 2 + 2 * LQ * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_l128_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) { set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+      attr_done = true;
+    }
+    attn_bwd_l128_kernel<<<(unsigned)((int64_t)n_seq * H), 512, LDS, s>>>(
+      (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (const bf16_t*)o, (const bf16_t*)dout, lse,
+      (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, H);
+    MDLM_LAUNCH_CHECK();
+    return 0;
+  }
   attn_delta_kernel<<<(unsigned)((M * H * 8 + 255) / 256), 256, 0, s>>>((const bf16_t*)o, (const bf16_t*)dout, delta_ws, M, H, L);
   attn_bwd_dkdv_kernel<<<(unsigned)blocks, 256, 0, s>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (const bf16_t*)dout,
                                                         lse, delta_ws, (bf16_t*)dk, (bf16_t*)dv, H, L);
