@@ -75,17 +75,30 @@ def rank_seed(seed, rank_):
   return int(seed) + int(rank_)
 
 
+def _all_reduce(t, op):
+  """In-place all-reduce.  Device tensors go straight to RCCL; under any other
+  backend (gloo rehearsals of N ranks on one card) they are staged through
+  host memory: gloo's own device path is unreliable when ranks share a GPU."""
+  if t.is_cuda and dist.get_backend() != 'nccl':
+    host = t.cpu()
+    dist.all_reduce(host, op=op)
+    t.copy_(host)
+  else:
+    dist.all_reduce(t, op=op)
+  return t
+
+
 def all_reduce_sums(sums):
   """SUM all-reduce of the (2,) fp64 metric vector, in place."""
   if dist.is_initialized() and dist.get_world_size() > 1:
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    _all_reduce(sums, dist.ReduceOp.SUM)
   return sums
 
 
 def max_over_ranks(value, device):
   t = torch.tensor([float(value)], dtype=torch.float64, device=device)
   if dist.is_initialized() and dist.get_world_size() > 1:
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _all_reduce(t, dist.ReduceOp.MAX)
   return t.item()
 
 
@@ -93,6 +106,11 @@ def gather_tokens(x):
   """Optional all_gather of (B, L) int64 samples (8 KiB/sample)."""
   if not dist.is_initialized() or dist.get_world_size() == 1:
     return x
+  if x.is_cuda and dist.get_backend() != 'nccl':   # see _all_reduce
+    host = x.cpu()
+    out = [torch.empty_like(host) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, host)
+    return torch.cat(out, 0).to(x.device)
   out = [torch.empty_like(x) for _ in range(dist.get_world_size())]
   dist.all_gather(out, x)
   return torch.cat(out, 0)
