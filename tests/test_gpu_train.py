@@ -474,7 +474,8 @@ def test_ddp_two_ranks_match_accumulation(ops, tmp_path):
 
 
 @pytest.mark.parametrize('T,N,K,splits', [(1024, 256, 512, 3), (4096, 768, 768, None),
-                                          (64, 256, 256, 1), (2048, 512, 256, 7)])
+                                          (64, 256, 256, 1), (2048, 512, 256, 7),
+                                          (512, 30720, 256, 2)])   # the LM1B output layer's row count
 def test_gemm_tn_splitk(ops, T, N, K, splits):
   """Weight + bias gradient straight from token-major dY (T, N) and X (T, K):
   transposing LDS reads, uneven token ranges, padded leading dimensions."""
