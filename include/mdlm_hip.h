@@ -68,17 +68,28 @@ int mdlm_subs_argmax(const void* logits, int64_t ld, int dtype,
  *   q = p_x0 * (t - (t - dt)); q[mask] = t - dt (fp32, in that order);
  *   x_s = argmax_v q_v / (1e-10 - log(u_v + 1e-10)); carry-over of unmasked.
  * p_x0 (B*L, V) probabilities, ld elements per row.  t (B) fp32.  u: (B*L, V)
- * contiguous fp32 uniforms, or NULL to draw in-kernel (Philox4x32-10 keyed by
+ * contiguous fp32 uniforms, or NULL to draw in-kernel (Philox4x32-7 keyed by
  * seed; element (row, v) uses counter offset + row*ceil(V/4) + v/4, lane v%4 --
  * the same stream mdlm_philox_uniform writes).  changed (B) int32, may be
  * NULL: set to 1 when any token of the sample changed, else 0 (replaces the
- * host-side torch.allclose of diffusion.py:682).  fast_math != 0 selects the
- * hardware log/rcp approximations (throughput mode; not bit-exact). */
+ * host-side torch.allclose of diffusion.py:682).
+ * The DEFINING arithmetic of the race (what token ids are bit-exact to):
+ *   g = 1e-10f - RN(ln(u + 1e-10f)) (correctly rounded fp32 log), key = q / g
+ *   (IEEE fp32 division), argmax with torch semantics (NaN wins, first index on
+ *   ties).
+ * fast_math == 0 (or u supplied): every element in that arithmetic.
+ * fast_math != 0 with in-kernel uniforms: SAME token ids at lower cost -- the
+ *   columns are ranked by an approximate key (hardware log2 / rcp); a row whose
+ *   best and runner-up approximate keys are closer than a proven bound on the
+ *   error of the two arithmetics (or whose values leave the analysed range) is
+ *   re-evaluated in the defining arithmetic.  n_exact_rows (optional device
+ *   uint64): += number of rows that took the re-evaluation (diagnostic). */
 int mdlm_ddpm_cache_update(const void* p_x0, int64_t ld, int dtype,
                            const int64_t* x, const float* t, double dt,
                            const float* u, uint64_t seed, uint64_t offset,
                            int64_t* x_next, int32_t* changed, int B, int L,
-                           int V, int mask_index, int fast_math, void* stream);
+                           int V, int mask_index, int fast_math,
+                           uint64_t* n_exact_rows, void* stream);
 
 /* (a)+(b) fused from cached LOGITS: p_x0 = exp(logit - lse) is formed in
  * registers (diffusion.py:602 `.exp()` + 261-277), never written.  lse (B*L)
@@ -92,7 +103,7 @@ int mdlm_subs_ddpm_update(const void* logits, int64_t ld, int dtype,
                           double dt, const float* u, uint64_t seed,
                           uint64_t offset, int64_t* x_next, int32_t* changed,
                           int B, int L, int V, int mask_index, int fast_math,
-                          void* stream);
+                          uint64_t* n_exact_rows, void* stream);
 
 /* Generic masked-row categorical race from cached LOGITS, for the other two
  * samplers of the reference.  A masked position draws
@@ -116,7 +127,15 @@ int mdlm_subs_race_update(const void* logits, int64_t ld, int dtype,
                           const float* q_mask, const float* u, uint64_t seed,
                           uint64_t offset, int64_t* x_next, int32_t* changed,
                           int B, int L, int V, int mask_index, int fast_math,
-                          void* stream);
+                          uint64_t* n_exact_rows, void* stream);
+
+/* Diagnostic for the error budget of the fast_math race (tests only; no
+ * reference counterpart): for n uniform bit patterns rbits[i] (u = (rbits >> 8)
+ * * 2^-24, as the kernels form it) writes the approximate pass's g~ and
+ * log2(g~) and g_exact[i] = the defining g.  The exhaustive test over all 2^24
+ * uniforms pins the bounds quoted in csrc/sampler.hip. */
+int mdlm_race_key_probe(const uint32_t* rbits, float* g_fast, float* log2_g_fast,
+                        float* g_exact, int64_t n, void* stream);
 
 /* Discrete-time (T > 0) SUBS loss term, Diffusion._d3pm_loss,
  * diffusion.py:329-358, given neg_logp_x0 (B, L) = -log p_theta(x0 | xt) (the

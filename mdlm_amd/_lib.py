@@ -23,11 +23,12 @@ SIGNATURES = {
   'mdlm_subs_row_lse': [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp],
   'mdlm_subs_argmax': [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp],
   'mdlm_ddpm_cache_update': [_vp, _i64, _i32, _vp, _vp, _dbl, _vp, _u64, _u64,
-                             _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+                             _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
   'mdlm_subs_ddpm_update': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _dbl, _vp, _u64,
-                            _u64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+                            _u64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
   'mdlm_subs_race_update': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _u64,
-                            _u64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+                            _u64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+  'mdlm_race_key_probe': [_vp, _vp, _vp, _vp, _i64, _vp],
   'mdlm_d3pm_loss': [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp],
   'mdlm_lazy_select': [_vp, _vp, _dbl, _u64, _u64, _i32, _i32, _i32, _i32, _vp, _vp,
                        _vp, _vp, _vp],

@@ -62,7 +62,13 @@ DEFAULTS = dict(
   sampling=dict(predictor='ddpm_cache', steps=128, noise_removal=True,
                 num_sample_batches=2, num_sample_log=2, semi_ar=False,
                 stride_length=1, num_strides=1,
-                # mdlm_amd extensions (result-identical knobs)
+                # mdlm_amd extensions.  Result-identical knobs (same token ids on
+                # the same random stream, checked bit for bit by the GPU tests):
+                # fused, cache_policy, masked_rows_only, and fast_math -- true
+                # ranks the race by approximate keys and re-evaluates near-ties
+                # in the defining arithmetic, false evaluates every element in it
+                # (include/mdlm_hip.h).  lazy_unmask is NOT result-identical
+                # (same law, different map from random numbers): opt-in.
                 fused=True, cache_policy='sample', fast_math=True,
                 masked_rows_only=True, lazy_unmask=False,
                 p_x0_dtype='bf16'),

@@ -124,7 +124,8 @@ __device__ __forceinline__ bool am_better(float av, int ai, float bv, int bi) {
   if (!an && av != bv) return av > bv;
   return ai < bi;
 }
-__device__ __forceinline__ int block_argmax(ArgMax a, float* smv, int* smi) {
+__device__ __forceinline__ int block_argmax(ArgMax a, float* smv, int* smi,
+                                            float* best_val = nullptr) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     float ov = __shfl_xor(a.v, o); int oi = __shfl_xor(a.i, o);
@@ -138,6 +139,7 @@ __device__ __forceinline__ int block_argmax(ArgMax a, float* smv, int* smi) {
   for (int k = 1; k < 4; ++k)
     if (am_better(smv[k], smi[k], bv, bi)) { bv = smv[k]; bi = smi[k]; }
   __syncthreads();
+  if (best_val) *best_val = bv;
   return bi;
 }
 
@@ -347,73 +349,41 @@ __global__ __launch_bounds__(NT) void subs_argmax_kernel(
 }
 
 // ----------------------------------------- (b) ddpm_cache update / Gumbel race
-template <bool FAST>
-__device__ __forceinline__ float race(float q, float u) {
-  // diffusion.py:25-28: q / (1e-10 - log(u + 1e-10))
-  if constexpr (FAST) {
-    const float g = 1e-10f - __logf(u + 1e-10f);
-    return __fdividef(q, g);
-  } else {
-    // log in fp64, rounded once: correctly rounded fp32 log
-    const float g = 1e-10f - (float)log((double)(u + 1e-10f));
-    return q / g;
-  }
+// The race of diffusion.py:24-28 in its DEFINING arithmetic (what every token id
+// is bit-exact to):  key_v = q_v / g_v  (IEEE fp32 division),
+//   g_v = 1e-10f - RN(ln(u_v + 1e-10f))   (correctly rounded: fp64 log, rounded once)
+//   q_v = p_v * factor (fp32), q_mask = ms;  SRC 1: p_v = expf(logit_v - lse).
+// argmax with torch semantics (NaN is the maximum, first index wins ties).
+__device__ __forceinline__ float gumbel_norm_exact(float u) {
+  return 1e-10f - (float)log((double)(u + 1e-10f));
+}
+__device__ __forceinline__ float race_exact(float q, float u) {
+  return q / gumbel_norm_exact(u);
 }
 
 // SRC 0: row holds probabilities p_x0.  SRC 1: row holds raw logits + lse.
-template <int SRC, bool FAST>
+template <int SRC>
 __device__ __forceinline__ float q_of(float x, int v, int mask, float lse,
                                       float factor, float ms) {
   if (v == mask) return ms;  // diffusion.py:606
   float p;
   if constexpr (SRC == 0) p = x;
-  else p = FAST ? __expf(x - lse) : expf(x - lse);
+  else p = expf(x - lse);
   return p * factor;  // diffusion.py:605
 }
 
-template <typename T, int SRC, bool FAST, bool PHILOX>
-__global__ __launch_bounds__(NT) void ddpm_update_kernel(
-    const T* __restrict__ src, int64_t ld, float* __restrict__ lse_arr,
-    const int32_t* __restrict__ fresh,
-    const int64_t* __restrict__ x, const float* __restrict__ t, float dt,
-    const float* __restrict__ q_scale, const float* __restrict__ q_mask,
-    const float* __restrict__ u, uint64_t seed, uint64_t offset,
-    int64_t* __restrict__ x_next, int32_t* __restrict__ changed, int L, int V,
-    int mask) {
-  __shared__ float smv[4]; __shared__ int smi[4];
+// One row of the race in the defining arithmetic; result in all threads.
+template <typename T, int SRC, bool PHILOX>
+__device__ __forceinline__ int exact_row_race(
+    const T* __restrict__ row, int V, int mask, float lse, float factor, float ms,
+    const float* __restrict__ urow, uint64_t seed, uint64_t ctr0, float* smv,
+    int* smi) {
   constexpr int EPV = vec_traits<T>::EPV;
-  const int64_t r = blockIdx.x;
-  const int64_t tok = x[r];
-  if (tok != mask) {  // carry-over, diffusion.py:609-610
-    if (threadIdx.x == 0) x_next[r] = tok;
-    return;
-  }
-  const int b = (int)(r / L);
-  float ms, factor;
-  if (q_scale) {   // generic race: q_v = p_v * q_scale[b], q_mask = q_mask[b]
-    factor = q_scale[b]; ms = q_mask[b];
-  } else {
-    const float mt = t[b];
-    ms = mt - dt;          // diffusion.py:599 (fp32)
-    factor = mt - ms;      // diffusion.py:605 (not fp32(dt))
-  }
-  const T* row = src + r * ld;
-  float lse = 0.f;
-  if constexpr (SRC == 1) {
-    if (fresh && fresh[b]) {  // logits of this sample are new: (re)compute the row lse
-      __shared__ float sml[9];
-      lse = subs_row_lse<T>(row, V, mask, sml);
-      if (threadIdx.x == 0) lse_arr[r] = lse;
-    } else {
-      lse = lse_arr[r];
-    }
-  }
   ArgMax am;
-  const uint64_t G = (uint64_t)((V + 3) >> 2);
-  const uint64_t ctr0 = offset + (uint64_t)r * G;
+  const int G = (V + 3) >> 2;
   if constexpr (PHILOX) {
     if (row_head(row, V) == 0) {
-      // aligned fast path: 16-byte loads, EPV/4 Philox groups per vector
+      // aligned rows: 16-byte loads, EPV/4 Philox groups per vector
       const int nvec = V / EPV;
       const uint4* vp = reinterpret_cast<const uint4*>(row);
       for (int i = threadIdx.x; i < nvec; i += NT) {
@@ -426,69 +396,167 @@ __global__ __launch_bounds__(NT) void ddpm_update_kernel(
           const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float q = q_of<SRC, FAST>(f[gq * 4 + k], v0 + k, mask, lse, factor, ms);
-            am.put(race<FAST>(q, Philox::u01(rr[k])), v0 + k);
+            const float q = q_of<SRC>(f[gq * 4 + k], v0 + k, mask, lse, factor, ms);
+            am.put(race_exact(q, Philox::u01(rr[k])), v0 + k);
           }
         }
       }
       for (int v = nvec * EPV + threadIdx.x; v < V; v += NT) {
         const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)(v >> 2));
         const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
-        const float q = q_of<SRC, FAST>(elem<T>::load(row + v), v, mask, lse, factor, ms);
-        am.put(race<FAST>(q, Philox::u01(rr[v & 3])), v);
+        const float q = q_of<SRC>(elem<T>::load(row + v), v, mask, lse, factor, ms);
+        am.put(race_exact(q, Philox::u01(rr[v & 3])), v);
       }
     } else {
       // unaligned rows: one Philox group (4 consecutive columns) per thread
-      for (int g = threadIdx.x; g < (int)G; g += NT) {
+      for (int g = threadIdx.x; g < G; g += NT) {
         const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)g);
         const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int v = g * 4 + k;
           if (v < V) {
-            const float q = q_of<SRC, FAST>(elem<T>::load(row + v), v, mask, lse, factor, ms);
-            am.put(race<FAST>(q, Philox::u01(rr[k])), v);
+            const float q = q_of<SRC>(elem<T>::load(row + v), v, mask, lse, factor, ms);
+            am.put(race_exact(q, Philox::u01(rr[k])), v);
           }
         }
       }
     }
   } else {
-    const float* urow = u + r * (int64_t)V;
     for (int v = threadIdx.x; v < V; v += NT) {
-      const float q = q_of<SRC, FAST>(elem<T>::load(row + v), v, mask, lse, factor, ms);
-      am.put(race<FAST>(q, urow[v]), v);
+      const float q = q_of<SRC>(elem<T>::load(row + v), v, mask, lse, factor, ms);
+      am.put(race_exact(q, urow[v]), v);
     }
   }
-  const int best = block_argmax(am, smv, smi);
+  return block_argmax(am, smv, smi);
+}
+
+// Per-sample race weights: ddpm_cache (diffusion.py:598-606) or the generic pair.
+__device__ __forceinline__ void race_weights(const float* t, float dt,
+                                             const float* q_scale,
+                                             const float* q_mask, int b,
+                                             float& factor, float& ms) {
+  if (q_scale) {   // generic race: q_v = p_v * q_scale[b], q_mask = q_mask[b]
+    factor = q_scale[b]; ms = q_mask[b];
+  } else {
+    const float mt = t[b];
+    ms = mt - dt;          // diffusion.py:599 (fp32)
+    factor = mt - ms;      // diffusion.py:605 (not fp32(dt))
+  }
+}
+
+// Reference kernel of the race: every element in the defining arithmetic.  Used
+// when the uniforms are supplied (`u`), or on request (fast_math = 0).
+template <typename T, int SRC, bool PHILOX>
+__global__ __launch_bounds__(NT) void ddpm_update_kernel(
+    const T* __restrict__ src, int64_t ld, float* __restrict__ lse_arr,
+    const int32_t* __restrict__ fresh,
+    const int64_t* __restrict__ x, const float* __restrict__ t, float dt,
+    const float* __restrict__ q_scale, const float* __restrict__ q_mask,
+    const float* __restrict__ u, uint64_t seed, uint64_t offset,
+    int64_t* __restrict__ x_next, int32_t* __restrict__ changed, int L, int V,
+    int mask) {
+  __shared__ float smv[4]; __shared__ int smi[4];
+  const int64_t r = blockIdx.x;
+  const int64_t tok = x[r];
+  if (tok != mask) {  // carry-over, diffusion.py:609-610
+    if (threadIdx.x == 0) x_next[r] = tok;
+    return;
+  }
+  const int b = (int)(r / L);
+  float ms, factor;
+  race_weights(t, dt, q_scale, q_mask, b, factor, ms);
+  const T* row = src + r * ld;
+  float lse = 0.f;
+  if constexpr (SRC == 1) {
+    if (fresh && fresh[b]) {  // logits of this sample are new: (re)compute the row lse
+      __shared__ float sml[9];
+      lse = subs_row_lse<T>(row, V, mask, sml);
+      if (threadIdx.x == 0) lse_arr[r] = lse;
+    } else {
+      lse = lse_arr[r];
+    }
+  }
+  const uint64_t ctr0 = offset + (uint64_t)r * (uint64_t)((V + 3) >> 2);
+  const int best = exact_row_race<T, SRC, PHILOX>(
+      row, V, mask, lse, factor, ms, PHILOX ? nullptr : u + r * (int64_t)V, seed,
+      ctr0, smv, smi);
   if (threadIdx.x == 0) {
     x_next[r] = best;
     if (best != mask && changed) changed[b] = 1;  // benign race: all write 1
   }
 }
 
-// Throughput variant of the race (fast_math + in-kernel Philox).  Same draw
-// u_v, same winner up to floating-point near-ties, fewer transcendentals:
-//   argmax_v q_v / g_v,  g_v = 1e-10 - ln(u_v + 1e-10)
-// SRC 1 (logits): q_v = exp(l_v - lse) f  ->  compare in the log2 domain
-//   key_v = l_v log2(e) - log2(g_v)                      (2 x v_log_f32)
-//   key_mask = log2(ms) - log2(g_mask) + lse log2(e) - log2(f)
-// SRC 0 (probabilities): key_v = p_v f / g_v            (v_log_f32 + v_rcp_f32)
-// No NaN ordering (inputs are finite); branch-free running maximum.
+// ---- throughput path: SAME winner, cheaper arithmetic -------------------------
+// Pass 1 ranks the columns by an approximate key with fewer transcendentals
+// (hardware v_log_f32 / v_rcp_f32, <= 1 ulp each):
+//   SRC 1 (logits), log2 domain:  k~_v = l_v log2(e) - log2(g~_v)     (2 x v_log_f32)
+//                                 k~_mask = c_mask - log2(g~_mask),
+//                                 c_mask = log2(ms) - log2(factor) + lse log2(e)
+//   SRC 0 (probabilities):        k~_v = p_v factor / g~_v            (v_log_f32 + v_rcp_f32)
+//   g~ = fma(-ln 2, v_log_f32(u + 1e-10f), 1e-10f)
+// and keeps, per row, the best key B and the best key of any OTHER column C.
+// Error budget (SRC 1; D_v = log2 of the defining key + lse log2(e) - log2(factor),
+// in real arithmetic; ulp-sized terms as multiples of e = 2^-24):
+//   pass 1:  |log2(g~) - log2(g)| <= 5 e max(1, |log2 g|) <= 121 e  (measured over ALL 2^24
+//            uniforms: 4.47, tests/test_gpu_sampler.py::test_race_key_error_exhaustive; |log2 g| <= 24.1),
+//            fma rounding e |k~|, fp32 log2(e) constant 0.5 e |l_v| log2(e);
+//   defining arithmetic:  RN(l - lse) -> 1.45 e |l - lse|; expf 1 ulp, two roundings -> 5.8 e.
+//   With |l_v| log2(e) <= |k~_v| + 24.1 and |l_v - lse| log2(e) <= |k~_v| + 24.1 + |lse| log2(e):
+//   |k~_v - D_v| <= e (2.5 |k~_v| + 1.45 |lse| log2(e) + 165);  the mask column instead has the
+//   three v_log_f32 and two additions of c_mask:  <= e (3 |k~| + 3 |lse| log2(e) + 210).
+// If B - C > thr = 2^-20 (|B| + |lse| log2(e) + 64) = e (16 |B| + 16 |lse| log2(e) + 1024)
+// (>= 2.7x the sum of two such bounds) the approximate winner has the strictly largest
+// defining key, so it IS the reference argmax.  Otherwise (probability ~ thr ln 2 ~ 1e-4 of
+// the rows in which two tokens compete, far fewer while the mask column dominates), or when
+// the row is outside the analysed range (non-finite lse / weights, winner key near the fp32
+// underflow range, where the defining arithmetic loses relative precision), the whole row is
+// re-evaluated in the defining arithmetic (exact_row_race).  Hence: bit-identical token ids
+// to ddpm_update_kernel on the same Philox stream, at the cost of the approximate pass.
+// SRC 0: same scheme in the linear domain, relative threshold 2^-18 = 64 e (budget per key:
+// g~ vs g 6 e -- measured over all 2^24 uniforms by the same test: 2.9 --, v_rcp_f32 2 e,
+// four roundings 4 e -> 12 e).
+//
+// Prefilter (SRC 1, q_mask > 0).  While the mask column carries most of the mass (every
+// ddpm_cache step but the last few) almost no column can beat ITS key, which is known
+// before the row is read: bar = k~_mask.  -ln(s) >= 1 - s gives g_v >= 1 - u_v, and
+// 1 - u_v > 2^(-1 - n_v) with n_v the number of leading bits of the 32 random bits r_v that
+// equal its top bit (n_v leading ones: u_v < 1 - 2^-n_v; leading zeros: u_v < 1/2, g_v > ln 2).
+// So k_v < l_v log2(e) + 1 + n_v, and a column with
+//     l_v log2(e) + n_v < bar - margin - 1,   margin = 1 + 2^-18 (|bar| + |lse| log2(e) + 64)
+// lies more than `margin` >= thr + (every rounding above) below B >= bar: it can neither win
+// nor tie, in either arithmetic, and skips both logarithms (4.5 full-rate VALU operations
+// instead of 2 quarter-rate + 8 full-rate ones).  A vector of 8 columns is evaluated in full
+// as soon as the largest of its 8 bounds passes the test.
 struct FastRace {
-  float best = -INFINITY; int idx = 0x7fffffff;
+  float best = -INFINITY, sec = -INFINITY; int idx = 0x7fffffff;
   __device__ __forceinline__ void put(float k, int i) {
-    const bool take = k > best;   // ascending i per thread: first index wins ties
+    // sec <= best always, so the median of (best, k, sec) is the new runner-up
+    sec = __builtin_amdgcn_fmed3f(best, k, sec);
+    const bool take = k > best;   // any tie ends in the exact re-evaluation
     best = take ? k : best; idx = take ? i : idx;
   }
 };
 
-template <int SRC>
-__device__ __forceinline__ float fast_key(float x, unsigned rbits, float factor) {
+__device__ __forceinline__ float fast_gumbel_norm(unsigned rbits) {
   const float u = Philox::u01(rbits);
   const float a = __builtin_amdgcn_logf(u + 1e-10f);              // log2
-  const float g = __builtin_fmaf(-0.6931471805599453f, a, 1e-10f);
+  return __builtin_fmaf(-0.6931471805599453f, a, 1e-10f);
+}
+
+template <int SRC>
+__device__ __forceinline__ float fast_key(float x, unsigned rbits, float factor) {
+  const float g = fast_gumbel_norm(rbits);
   if constexpr (SRC == 1) return __builtin_fmaf(x, 1.4426950408889634f, -__builtin_amdgcn_logf(g));
   else return x * factor * __builtin_amdgcn_rcpf(g);
+}
+
+// prefilter: upper bound l_v log2(e) + n_v of (k_v - 1) for one column (see above)
+__device__ __forceinline__ float key_bound(float x, unsigned rbits) {
+  // v_ffbh_i32: leading bits equal to the top bit; -1 (-> 4.29e9 as unsigned) if all are
+  unsigned n;   // (no clang builtin for this instruction)
+  asm("v_ffbh_i32 %0, %1" : "=v"(n) : "v"(rbits));
+  return __builtin_fmaf(x, 1.4426950408889634f, (float)n);
 }
 
 template <typename T, int SRC>
@@ -498,8 +566,10 @@ __global__ __launch_bounds__(NT) void ddpm_update_fast_kernel(
     const int64_t* __restrict__ x, const float* __restrict__ t, float dt,
     const float* __restrict__ q_scale, const float* __restrict__ q_mask,
     uint64_t seed, uint64_t offset, int64_t* __restrict__ x_next,
-    int32_t* __restrict__ changed, int L, int V, int mask) {
+    int32_t* __restrict__ changed, int L, int V, int mask,
+    unsigned long long* __restrict__ n_exact) {
   __shared__ float smv[4]; __shared__ int smi[4];
+  __shared__ int sm_near;
   constexpr int EPV = vec_traits<T>::EPV;
   const int64_t r = blockIdx.x;
   const int64_t tok = x[r];
@@ -509,16 +579,10 @@ __global__ __launch_bounds__(NT) void ddpm_update_fast_kernel(
   }
   const int b = (int)(r / L);
   float ms, factor;
-  if (q_scale) {   // generic race: q_v = p_v * q_scale[b], q_mask = q_mask[b]
-    factor = q_scale[b]; ms = q_mask[b];
-  } else {
-    const float mt = t[b];
-    ms = mt - dt;          // diffusion.py:599 (fp32)
-    factor = mt - ms;      // diffusion.py:605
-  }
+  race_weights(t, dt, q_scale, q_mask, b, factor, ms);
   const T* row = src + r * ld;
-  const uint64_t G = (uint64_t)((V + 3) >> 2);
-  const uint64_t ctr0 = offset + (uint64_t)r * G;
+  const int G = (V + 3) >> 2;
+  const uint64_t ctr0 = offset + (uint64_t)r * (uint64_t)G;
   float lse_r = 0.f;
   if constexpr (SRC == 1) {
     if (fresh && fresh[b]) {  // new logits: one extra pass for the row lse (L2-warm after it)
@@ -529,70 +593,139 @@ __global__ __launch_bounds__(NT) void ddpm_update_fast_kernel(
       lse_r = lse_arr[r];
     }
   }
-  // key of the mask column given its random bits (diffusion.py:606: q = ms)
-  auto mask_key = [&](unsigned rbits) -> float {
-    const float u = Philox::u01(rbits);
-    const float g = __builtin_fmaf(-0.6931471805599453f, __builtin_amdgcn_logf(u + 1e-10f), 1e-10f);
-    if constexpr (SRC == 1) {
-      if (!(ms > 0.f)) return -INFINITY;
-      return __builtin_amdgcn_logf(ms) - __builtin_amdgcn_logf(g) +
-             lse_r * 1.4426950408889634f - __builtin_amdgcn_logf(factor);
+  if (threadIdx.x == 0) sm_near = 0;
+  // rows outside the analysed range go straight to the defining arithmetic
+  // (block-uniform: all operands are per-row values)
+  bool exact = !(factor > 0x1p-60f && factor < 0x1p60f) || !(ms < 0x1p60f) ||
+               !(fabsf(lse_r) < 0x1p60f);
+  int best = 0;
+  if (!exact) {
+    const float lse2 = lse_r * 1.4426950408889634f;
+    // key of the mask column (diffusion.py:606: q = ms), from its own random bits
+    float kmask;
+    {
+      const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)(mask >> 2));
+      const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
+      const float g = fast_gumbel_norm(rr[mask & 3]);
+      if constexpr (SRC == 1) {
+        // q_mask <= 0 never beats a positive key
+        kmask = ms > 0.f ? (__builtin_amdgcn_logf(ms) - __builtin_amdgcn_logf(factor) + lse2) -
+                               __builtin_amdgcn_logf(g)
+                         : -INFINITY;
+      } else {
+        kmask = ms * __builtin_amdgcn_rcpf(g);
+      }
+    }
+    FastRace fr;
+    if (threadIdx.x == 0) fr.put(kmask, mask);
+    float acc = 0.f;   // SRC 0: NaN / inf detector (any non-finite key poisons the sum)
+    // SRC 1: a column passes when l_v log2(e) + n_v >= c_bar = bar - margin - 1;
+    // -inf (no usable bar) lets every column through
+    const float c_bar = (SRC == 1 && kmask > -INFINITY)
+        ? kmask - 2.f - 0x1p-18f * (fabsf(kmask) + fabsf(lse2) + 64.f) : -INFINITY;
+    // the mask column's own key was put above; its row entry never competes
+    // (SRC 0: 0 rather than -inf so that it does not trip the non-finite detector)
+    auto key_of = [&](float xv, unsigned rbits, int v) -> float {
+      return v == mask ? (SRC == 1 ? -INFINITY : 0.f) : fast_key<SRC>(xv, rbits, factor);
+    };
+    if (row_head(row, V) == 0) {
+      const int nvec = V / EPV;
+      const uint4* vp = reinterpret_cast<const uint4*>(row);
+      for (int i = threadIdx.x; i < nvec; i += NT) {
+        float f[EPV];
+        unpack<T>(vp[i], f);
+        const int v0 = i * EPV;
+        unsigned rb[EPV];
+#pragma unroll
+        for (int gq = 0; gq < EPV / 4; ++gq) {
+          const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)((v0 >> 2) + gq));
+          rb[gq * 4 + 0] = rn.x; rb[gq * 4 + 1] = rn.y;
+          rb[gq * 4 + 2] = rn.z; rb[gq * 4 + 3] = rn.w;
+        }
+        bool go = true;
+        if constexpr (SRC == 1) {
+          float hi = key_bound(f[0], rb[0]);
+#pragma unroll
+          for (int k = 1; k < EPV; ++k) hi = fmaxf(hi, key_bound(f[k], rb[k]));
+          go = hi >= c_bar;
+        }
+        if (go) {
+          float key[EPV];
+#pragma unroll
+          for (int k = 0; k < EPV; ++k) key[k] = key_of(f[k], rb[k], v0 + k);
+#pragma unroll
+          for (int k = 0; k < EPV; ++k) {
+            fr.put(key[k], v0 + k);
+            if constexpr (SRC == 0) acc += key[k];
+          }
+        }
+      }
+      for (int v = nvec * EPV + threadIdx.x; v < V; v += NT) {
+        const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)(v >> 2));
+        const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
+        const float k = key_of(elem<T>::load(row + v), rr[v & 3], v);
+        fr.put(k, v);
+        if constexpr (SRC == 0) acc += k;
+      }
     } else {
-      return ms * __builtin_amdgcn_rcpf(g);
-    }
-  };
-  FastRace fr;
-  if (row_head(row, V) == 0) {
-    const int nvec = V / EPV;
-    const uint4* vp = reinterpret_cast<const uint4*>(row);
-    for (int i = threadIdx.x; i < nvec; i += NT) {
-      float f[EPV];
-      unpack<T>(vp[i], f);
-      const int v0 = i * EPV;
-      float key[EPV];
+      for (int g = threadIdx.x; g < G; g += NT) {
+        const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)g);
+        const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
 #pragma unroll
-      for (int gq = 0; gq < EPV / 4; ++gq) {
-        const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)((v0 >> 2) + gq));
-        key[gq * 4 + 0] = fast_key<SRC>(f[gq * 4 + 0], rn.x, factor);
-        key[gq * 4 + 1] = fast_key<SRC>(f[gq * 4 + 1], rn.y, factor);
-        key[gq * 4 + 2] = fast_key<SRC>(f[gq * 4 + 2], rn.z, factor);
-        key[gq * 4 + 3] = fast_key<SRC>(f[gq * 4 + 3], rn.w, factor);
-        if ((unsigned)(mask - (v0 + gq * 4)) < 4u) {  // rare: the mask column is in this group
-          const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
-          key[gq * 4 + (mask & 3)] = mask_key(rr[mask & 3]);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < EPV; ++k) fr.put(key[k], v0 + k);
-    }
-    for (int v = nvec * EPV + threadIdx.x; v < V; v += NT) {
-      const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)(v >> 2));
-      const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
-      const float k = v == mask ? mask_key(rr[v & 3])
-                                : fast_key<SRC>(elem<T>::load(row + v), rr[v & 3], factor);
-      fr.put(k, v);
-    }
-  } else {
-    for (int g = threadIdx.x; g < (int)G; g += NT) {
-      const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)g);
-      const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int v = g * 4 + k;
-        if (v < V) {
-          const float kk = v == mask ? mask_key(rr[k])
-                                     : fast_key<SRC>(elem<T>::load(row + v), rr[k], factor);
-          fr.put(kk, v);
+        for (int k = 0; k < 4; ++k) {
+          const int v = g * 4 + k;
+          if (v < V) {
+            const float kk = key_of(elem<T>::load(row + v), rr[k], v);
+            fr.put(kk, v);
+            if constexpr (SRC == 0) acc += kk;
+          }
         }
       }
     }
+    ArgMax am; am.v = fr.best; am.i = fr.idx;
+    float B;
+    best = block_argmax(am, smv, smi, &B);
+    // runner-up seen from this thread: its own best unless it holds the winner
+    const float C = fr.idx == best ? fr.sec : fr.best;
+    bool near;
+    if constexpr (SRC == 1) {
+      const float thr = 0x1p-20f * (fabsf(B) + fabsf(lse2) + 64.f);
+      near = !(C < B - thr);
+      // log2 of the winner's probability is >= B - lse2 - 24.1; keep p, p*factor and
+      // the key well inside the normal fp32 range
+      if (threadIdx.x == 0 &&
+          !(B - lse2 + fminf(0.f, __builtin_amdgcn_logf(factor)) > -90.f)) near = true;
+    } else {
+      near = !(C < B - 0x1p-18f * fabsf(B)) || !(fabsf(acc) < INFINITY);
+      if (threadIdx.x == 0 && !(B > 0x1p-90f)) near = true;
+    }
+    if (near) sm_near = 1;   // benign race: all write 1
+    __syncthreads();
+    exact = sm_near != 0;
   }
-  ArgMax am; am.v = fr.best; am.i = fr.idx;
-  const int best = block_argmax(am, smv, smi);
+  if (exact) {   // block-uniform
+    best = exact_row_race<T, SRC, true>(row, V, mask, lse_r, factor, ms, nullptr,
+                                        seed, ctr0, smv, smi);
+    if (threadIdx.x == 0 && n_exact) atomicAdd(n_exact, 1ull);
+  }
   if (threadIdx.x == 0) {
     x_next[r] = best;
     if (best != mask && changed) changed[b] = 1;  // benign race: all write 1
   }
+}
+
+// Diagnostic for the error budget above (tests only; no reference counterpart):
+// for uniform bit patterns rbits[i] (u = (rbits >> 8) 2^-24) writes the pass-1 values
+// g~ and log2(g~) and the defining g = 1e-10f - RN(ln(u + 1e-10f)).
+__global__ void race_key_probe_kernel(const uint32_t* __restrict__ rbits,
+                                      float* __restrict__ g_fast,
+                                      float* __restrict__ log2_g_fast,
+                                      float* __restrict__ g_exact, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g_fast[i] = fast_gumbel_norm(rbits[i]);
+  log2_g_fast[i] = __builtin_amdgcn_logf(fast_gumbel_norm(rbits[i]));
+  g_exact[i] = gumbel_norm_exact(Philox::u01(rbits[i]));
 }
 
 // Discrete-time SUBS loss term, diffusion.py:329-358.  For SUBS outputs the
@@ -973,7 +1106,8 @@ static int launch_update(const void* src, int64_t ld, int dtype, float* lse,
                          const float* q_scale, const float* q_mask,
                          const float* u, uint64_t seed, uint64_t offset,
                          int64_t* x_next, int32_t* changed, int B, int L, int V,
-                         int mask_index, int fast_math, void* stream) {
+                         int mask_index, int fast_math, uint64_t* n_exact_rows,
+                         void* stream) {
   const char* nm = q_scale ? "subs_race_update" : SRC ? "subs_ddpm_update" : "ddpm_cache_update";
   if (B == 0) return 0;
   MDLM_CHECK_ARG(src && x && (t || q_scale) && x_next, "%s: null pointer", nm);
@@ -982,7 +1116,6 @@ static int launch_update(const void* src, int64_t ld, int dtype, float* lse,
   MDLM_CHECK_ARG(B >= 0 && L > 0 && V > 0 && ld >= V && (int64_t)B * L < (1ll << 31), "%s: bad shape B=%d L=%d V=%d ld=%lld", nm, B, L, V, (long long)ld);
   MDLM_CHECK_ARG(mask_index >= 0 && mask_index < V, "%s: mask_index out of range", nm);
   MDLM_CHECK_ARG(dtype == MDLM_F32 || dtype == MDLM_BF16, "%s: bad dtype", nm);
-  if (B == 0) return 0;
   hipStream_t s = ST(stream);
   if (changed) {
     hipError_t e = hipMemsetAsync(changed, 0, sizeof(int32_t) * (size_t)B, s);
@@ -990,20 +1123,19 @@ static int launch_update(const void* src, int64_t ld, int dtype, float* lse,
   }
   const unsigned rows = (unsigned)((int64_t)B * L);
   const float dtf = (float)dt;  // python float -> fp32 scalar, as torch does
-#define MDLM_UPD(T, FAST, PH) \
-  ddpm_update_kernel<T, SRC, FAST, PH><<<rows, NT, 0, s>>>((const T*)src, ld, lse, fresh, x, t, dtf, q_scale, q_mask, u, seed, offset, x_next, changed, L, V, mask_index)
+  unsigned long long* nx = reinterpret_cast<unsigned long long*>(n_exact_rows);
+#define MDLM_UPD(T, PH) \
+  ddpm_update_kernel<T, SRC, PH><<<rows, NT, 0, s>>>((const T*)src, ld, lse, fresh, x, t, dtf, q_scale, q_mask, u, seed, offset, x_next, changed, L, V, mask_index)
   const bool ph = (u == nullptr), fast = fast_math != 0;
   if (ph && fast) {
     if (dtype == MDLM_F32)
-      ddpm_update_fast_kernel<float, SRC><<<rows, NT, 0, s>>>((const float*)src, ld, lse, fresh, x, t, dtf, q_scale, q_mask, seed, offset, x_next, changed, L, V, mask_index);
+      ddpm_update_fast_kernel<float, SRC><<<rows, NT, 0, s>>>((const float*)src, ld, lse, fresh, x, t, dtf, q_scale, q_mask, seed, offset, x_next, changed, L, V, mask_index, nx);
     else
-      ddpm_update_fast_kernel<bf16_t, SRC><<<rows, NT, 0, s>>>((const bf16_t*)src, ld, lse, fresh, x, t, dtf, q_scale, q_mask, seed, offset, x_next, changed, L, V, mask_index);
+      ddpm_update_fast_kernel<bf16_t, SRC><<<rows, NT, 0, s>>>((const bf16_t*)src, ld, lse, fresh, x, t, dtf, q_scale, q_mask, seed, offset, x_next, changed, L, V, mask_index, nx);
   } else if (dtype == MDLM_F32) {
-    if (ph) { if (fast) MDLM_UPD(float, true, true); else MDLM_UPD(float, false, true); }
-    else    { if (fast) MDLM_UPD(float, true, false); else MDLM_UPD(float, false, false); }
+    if (ph) MDLM_UPD(float, true); else MDLM_UPD(float, false);
   } else {
-    if (ph) { if (fast) MDLM_UPD(bf16_t, true, true); else MDLM_UPD(bf16_t, false, true); }
-    else    { if (fast) MDLM_UPD(bf16_t, true, false); else MDLM_UPD(bf16_t, false, false); }
+    if (ph) MDLM_UPD(bf16_t, true); else MDLM_UPD(bf16_t, false);
   }
 #undef MDLM_UPD
   MDLM_LAUNCH_CHECK();
@@ -1015,8 +1147,8 @@ extern "C" int mdlm_ddpm_cache_update(const void* p_x0, int64_t ld, int dtype,
                                       const float* u, uint64_t seed, uint64_t offset,
                                       int64_t* x_next, int32_t* changed, int B,
                                       int L, int V, int mask_index, int fast_math,
-                                      void* stream) {
-  return launch_update<0>(p_x0, ld, dtype, nullptr, nullptr, x, t, dt, nullptr, nullptr, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
+                                      uint64_t* n_exact_rows, void* stream) {
+  return launch_update<0>(p_x0, ld, dtype, nullptr, nullptr, x, t, dt, nullptr, nullptr, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, n_exact_rows, stream);
 }
 
 extern "C" int mdlm_subs_ddpm_update(const void* logits, int64_t ld, int dtype,
@@ -1026,8 +1158,8 @@ extern "C" int mdlm_subs_ddpm_update(const void* logits, int64_t ld, int dtype,
                                      uint64_t seed, uint64_t offset,
                                      int64_t* x_next, int32_t* changed, int B,
                                      int L, int V, int mask_index, int fast_math,
-                                     void* stream) {
-  return launch_update<1>(logits, ld, dtype, lse, fresh, x, t, dt, nullptr, nullptr, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
+                                     uint64_t* n_exact_rows, void* stream) {
+  return launch_update<1>(logits, ld, dtype, lse, fresh, x, t, dt, nullptr, nullptr, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, n_exact_rows, stream);
 }
 
 extern "C" int mdlm_subs_race_update(const void* logits, int64_t ld, int dtype,
@@ -1037,9 +1169,19 @@ extern "C" int mdlm_subs_race_update(const void* logits, int64_t ld, int dtype,
                                      uint64_t seed, uint64_t offset,
                                      int64_t* x_next, int32_t* changed, int B,
                                      int L, int V, int mask_index, int fast_math,
-                                     void* stream) {
+                                     uint64_t* n_exact_rows, void* stream) {
   MDLM_CHECK_ARG(q_scale && q_mask, "subs_race_update: q_scale / q_mask are required");
-  return launch_update<1>(logits, ld, dtype, lse, fresh, x, nullptr, 0.0, q_scale, q_mask, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, stream);
+  return launch_update<1>(logits, ld, dtype, lse, fresh, x, nullptr, 0.0, q_scale, q_mask, u, seed, offset, x_next, changed, B, L, V, mask_index, fast_math, n_exact_rows, stream);
+}
+
+extern "C" int mdlm_race_key_probe(const uint32_t* rbits, float* g_fast,
+                                   float* log2_g_fast, float* g_exact, int64_t n,
+                                   void* stream) {
+  MDLM_CHECK_ARG(rbits && g_fast && log2_g_fast && g_exact && n >= 0, "race_key_probe: bad args");
+  if (n == 0) return 0;
+  race_key_probe_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ST(stream)>>>(rbits, g_fast, log2_g_fast, g_exact, n);
+  MDLM_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int mdlm_philox_uniform(float* out, int64_t rows, int V, uint64_t seed,

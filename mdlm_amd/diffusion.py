@@ -11,7 +11,7 @@ methods `forward`, `_subs_parameterization`, `_process_sigma`, `q_xt`,
 `_forward_pass_diffusion`, `_loss`, `_compute_loss`, `validation_step`.
 
 Extensions (keyword-only, allowed by the north star): supplied uniform noise
-`u=` for parity runs; otherwise uniforms come from an in-kernel Philox4x32-10
+`u=` for parity runs; otherwise uniforms come from an in-kernel Philox4x32-7
 stream keyed by (`config.seed` + rank, running offset).
 
 Also on the kernels: the `ddpm` and `analytic` samplers (`_ddpm_update`,

@@ -111,8 +111,10 @@ def _t_vec(t, B):
 
 
 def ddpm_cache_update(p_x0, x, t, dt, mask_index, u=None, seed=0, offset=0,
-                      changed=None, fast_math=False, x_next=None):
-  """(b) from probabilities.  Returns x_next (and fills `changed` (B,) int32)."""
+                      changed=None, fast_math=False, x_next=None, n_exact=None):
+  """(b) from probabilities.  Returns x_next (and fills `changed` (B,) int32).
+  fast_math: same token ids through the cheaper two-pass race (include/mdlm_hip.h);
+  n_exact (optional, device int64[1]) counts the rows it re-evaluated."""
   p, rows, V, ld = _rows2d(p_x0, 'p_x0')
   x = _dev(x, 'x', torch.int64).contiguous()
   B, L = x.shape
@@ -126,13 +128,13 @@ def ddpm_cache_update(p_x0, x, t, dt, mask_index, u=None, seed=0, offset=0,
   call('mdlm_ddpm_cache_update', p.data_ptr(), ld, _DT[p.dtype], x.data_ptr(),
        tt.data_ptr(), float(dt), _p(u), int(seed), int(offset),
        x_next.data_ptr(), _p(changed), B, L, V, int(mask_index),
-       int(bool(fast_math)), _stream())
+       int(bool(fast_math)), _p(n_exact), _stream())
   return x_next
 
 
 def subs_ddpm_update(logits, lse, x, t, dt, mask_index, u=None, seed=0,
                      offset=0, changed=None, fast_math=False, x_next=None,
-                     fresh=None):
+                     fresh=None, n_exact=None):
   """(a)+(b) fused from raw logits + row lse."""
   lg, rows, V, ld = _rows2d(logits, 'logits')
   x = _dev(x, 'x', torch.int64).contiguous()
@@ -149,13 +151,13 @@ def subs_ddpm_update(logits, lse, x, t, dt, mask_index, u=None, seed=0,
   call('mdlm_subs_ddpm_update', lg.data_ptr(), ld, _DT[lg.dtype],
        lse.data_ptr(), _p(fresh), x.data_ptr(), tt.data_ptr(), float(dt), _p(u),
        int(seed), int(offset), x_next.data_ptr(), _p(changed), B, L, V,
-       int(mask_index), int(bool(fast_math)), _stream())
+       int(mask_index), int(bool(fast_math)), _p(n_exact), _stream())
   return x_next
 
 
 def subs_race_update(logits, lse, x, q_scale, q_mask, mask_index, u=None,
                      seed=0, offset=0, changed=None, fast_math=False,
-                     x_next=None, fresh=None):
+                     x_next=None, fresh=None, n_exact=None):
   """Generic masked-row race (samplers 'ddpm' / 'analytic' / denoiser)."""
   lg, rows, V, ld = _rows2d(logits, 'logits')
   x = _dev(x, 'x', torch.int64).contiguous()
@@ -174,8 +176,19 @@ def subs_race_update(logits, lse, x, q_scale, q_mask, mask_index, u=None,
   call('mdlm_subs_race_update', lg.data_ptr(), ld, _DT[lg.dtype],
        lse.data_ptr(), _p(fresh), x.data_ptr(), qs.data_ptr(), qm.data_ptr(),
        _p(u), int(seed), int(offset), x_next.data_ptr(), _p(changed), B, L, V,
-       int(mask_index), int(bool(fast_math)), _stream())
+       int(mask_index), int(bool(fast_math)), _p(n_exact), _stream())
   return x_next
+
+
+def race_key_probe(rbits):
+  """Diagnostic: (g~ and log2 g~ of the approximate pass, defining g) for
+  uint32 bit patterns held in an int32 tensor."""
+  rbits = _dev(rbits, 'rbits', torch.int32).contiguous()
+  n = rbits.numel()
+  g, a, b = (torch.empty(n, dtype=torch.float32, device=rbits.device) for _ in range(3))
+  call('mdlm_race_key_probe', rbits.data_ptr(), g.data_ptr(), a.data_ptr(),
+       b.data_ptr(), n, _stream())
+  return g, a, b
 
 
 def d3pm_loss(neg_logp_x0, xt, t, T, mask_index, attn_mask=None):

@@ -29,8 +29,9 @@ def make_model(overrides=(), seed=5, vocab=V):
   from mdlm_amd.config import load_config
   from mdlm_amd.diffusion import Diffusion
   from mdlm_amd.tokenizer import SyntheticTokenizer
+  # default config: sampling.fast_math=true (the two-pass race, same token ids)
   cfg = load_config(['model=tiny', 'loader.eval_batch_size=3', 'sampling.steps=24',
-                     'sampling.fast_math=false', *overrides])
+                     *overrides])
   model = Diffusion(cfg, SyntheticTokenizer(vocab_size=vocab - 1, eos_token_id=7)).cuda()
   m = cfg.model
   p = orc.synthetic_dit_params(m.hidden_size, m.n_heads, m.n_blocks, m.cond_dim, vocab, seed=seed)
@@ -159,19 +160,19 @@ def test_cache_policies_and_reference_loop_agree(ops):
   assert outs['none'][1] == 3 * 25
 
 
-def test_fast_math_sampler_statistics(ops):
-  """Throughput mode (hardware log/rcp): same unmasking law, everything
-  unmasked after noise removal, deterministic in the seed."""
-  model, cfg, _ = make_model(['sampling.fast_math=true', 'loader.eval_batch_size=8'])
-  model.seed_rng(5)
-  a = model._sample(num_steps=32).cpu()
-  model.seed_rng(5)
-  b = model._sample(num_steps=32).cpu()
-  assert torch.equal(a, b) and (a != MASK).all()
-  nfe = int(model.last_nfe.item()) / 8
-  # expected NFE/sample = sum_i P(sample changed at step i) + 1
-  L, T = cfg.model.length, 32
-  assert 0.5 * T < nfe <= T + 1
+def test_fast_and_reference_race_emit_the_same_tokens(ops):
+  """`sampling.fast_math` only chooses HOW the race is evaluated (approximate
+  ranking + exact re-evaluation of near-ties vs every element in the defining
+  arithmetic): whole trajectories are identical, token for token, and so is the
+  number of backbone evaluations."""
+  outs = []
+  for fm in ('true', 'false'):
+    model, cfg, _ = make_model([f'sampling.fast_math={fm}', 'loader.eval_batch_size=8'])
+    model.seed_rng(5)
+    outs.append((model._sample(num_steps=32).cpu(), int(model.last_nfe.item())))
+  assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+  assert (outs[0][0] != MASK).all()
+  assert 0.5 * 32 < outs[0][1] / 8 <= 33
 
 
 def test_time_conditioning_path(ops):

@@ -158,20 +158,21 @@ def test_update_golden_full_vocab(ops):
   assert torch.equal(xn.cpu(), _t(g['full_x_next']))
 
 
-def _near_tie_only(q_over_g, got, ref, rel=1e-5):
-  """Mismatches are tolerated only where the two candidates are within `rel`."""
-  bad = (got != ref)
-  if not bad.any():
-    return True
-  a = q_over_g[bad].gather(-1, got[bad][:, None]).squeeze(-1)
-  b = q_over_g[bad].gather(-1, ref[bad][:, None]).squeeze(-1)
-  return bool(((a - b).abs() <= rel * b.abs()).all())
+def _exact_log_ok(u):
+  """True where torch's CPU fp32 log agrees with the correctly rounded log (the
+  defining arithmetic of the race, include/mdlm_hip.h) at u + 1e-10: all but
+  ~0.1 % of the uniforms.  Constructed near-ties use only such columns, so the
+  oracle's last bit is not in question."""
+  s = u + 1e-10
+  return s.log() == s.double().log().float()
 
 
 @pytest.mark.parametrize('aligned', [True, False])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_update_philox_matches_oracle(ops, aligned, dtype):
-  """In-kernel Philox path == oracle fed the same uniforms (bit-exact)."""
+  """In-kernel Philox path == oracle fed the same uniforms, bit-exact, for the
+  reference kernel (fast_math=False), the supplied-u path and the fast path
+  (fast_math=True: approximate ranking + exact re-evaluation of near-ties)."""
   torch.manual_seed(7)
   B, L = 3, 4
   logits = torch.randn(B, L, V_OWT) * 3
@@ -199,13 +200,153 @@ def test_update_philox_matches_oracle(ops, aligned, dtype):
   # supplied-u path gives the same answer
   xn2 = ops.ddpm_cache_update(dp, x.cuda(), t.cuda(), dt, MASK_OWT, u=u)
   assert torch.equal(xn2.cpu(), ref)
-  # fast-math path: identical except at near-ties
+  # fast path: identical token ids, no tolerance
+  changed.zero_()
   xf = ops.ddpm_cache_update(dp, x.cuda(), t.cuda(), dt, MASK_OWT, seed=seed,
-                             offset=off, fast_math=True)
-  tt = t[:, None, None]
-  q = p.float() * (tt - (tt - dt)); q[:, :, MASK_OWT] = (tt - dt)[:, :, 0]
-  r = q / (1e-10 - (u.cpu().view(B, L, V_OWT) + 1e-10).log())
-  assert _near_tie_only(r, xf.cpu(), ref)
+                             offset=off, fast_math=True, changed=changed)
+  assert torch.equal(xf.cpu(), ref)
+  assert torch.equal(changed.cpu(), (ref != x).any(-1).int())
+
+
+def test_race_key_error_exhaustive(ops):
+  """The error budget of the fast path (csrc/sampler.hip), measured over ALL
+  2^24 uniforms the kernels can draw: the approximate pass's log2(g~) against
+  log2 of the defining g = 1e-10f - RN(ln(u + 1e-10f)), and g~ against g; and
+  the device's defining g against the CPU's correctly rounded one."""
+  k = torch.arange(1 << 24, dtype=torch.int64)
+  rbits = (k << 8).to(torch.int32).cuda()        # same 32-bit patterns
+  g_fast, l2_fast, g_dev = (a.cpu() for a in ops.race_key_probe(rbits))
+  u = (k.double() / 16777216.0).float()          # Philox::u01
+  eps = torch.tensor(1e-10, dtype=torch.float32)
+  g_ref = eps - (u + eps).double().log().float()
+  assert int((g_ref != g_dev).sum()) == 0, 'defining g differs from RN(fp64 log)'
+  l2 = g_dev.double().log2()
+  assert -24.1 < l2.min().item() and l2.max().item() < 4.6
+  e = 2.0 ** -24
+  ratio = (l2_fast.double() - l2).abs() / (e * l2.abs().clamp(min=1.0))
+  assert ratio.max().item() <= 5.0, ratio.max().item()      # budget: 5 e max(1, |log2 g|)
+  rel = (g_fast.double() - g_dev.double()).abs() / g_dev.double()
+  assert rel.max().item() <= 6.0 * e, rel.max().item() / e   # budget: 6 e
+  # prefilter premise: g > 2^(-1 - n), n = leading bits of r equal to its top bit
+  r = (k << 8)
+  n_ones = 32 - torch.log2((((1 << 32) - 1) - r).clamp(min=1).double()).floor().long() - 1
+  n_zero = 32 - torch.log2(r.clamp(min=1).double()).floor().long() - 1
+  n = torch.where(r >= (1 << 31), n_ones, n_zero).clamp(max=32)
+  assert bool((g_dev.double() > torch.exp2(-1.0 - n.double())).all())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('from_logits', [False, True])
+def test_update_fast_is_bit_exact_full_vocab(ops, dtype, from_logits):
+  """>= 64 full-vocabulary rows x 3 seeds x two unmasking regimes: the fast path,
+  the reference kernel and the oracle (fed the kernel's own fp32 p_x0 when the
+  entry point starts from logits) pick identical tokens."""
+  torch.manual_seed(21)
+  B, L = 8, 8
+  logits = (torch.randn(B, L, V_OWT) * 3).to(dtype)
+  x = torch.full((B, L), MASK_OWT)
+  x[1, 2] = 5; x[6, 0] = 50256
+  dl = ops.alloc_logits(B, L, V_OWT, dtype); dl.copy_(logits)
+  lse = ops.subs_row_lse(dl, x.cuda(), MASK_OWT)
+  if from_logits:
+    p_dev = ops.subs_logprobs(dl, x.cuda(), MASK_OWT, out_dtype=torch.float32, as_probs=True)
+  else:
+    p_dev = ops.subs_logprobs(dl, x.cuda(), MASK_OWT, as_probs=True)   # p_x0 in `dtype`
+  p_cpu = p_dev.float().cpu()
+  dt = (1 - 1e-5) / 1000
+  n_exact = torch.zeros(1, dtype=torch.int64, device='cuda')
+  for t in (torch.linspace(1.0, 0.05, B), torch.full((B,), 2 * dt), torch.full((B,), 0.5 * dt)):
+    for seed in (1, 2, 3):
+      u = ops.philox_uniform(B * L, V_OWT, seed, 9).cpu().view(B, L, V_OWT)
+      _, ref = orc.ddpm_caching_update(None, x, t, dt, u, MASK_OWT, p_x0=p_cpu.clone())
+      for fast in (False, True):
+        if from_logits:
+          xn = ops.subs_ddpm_update(dl, lse, x.cuda(), t.cuda(), dt, MASK_OWT, seed=seed,
+                                    offset=9, fast_math=fast, n_exact=n_exact)
+        else:
+          xn = ops.ddpm_cache_update(p_dev, x.cuda(), t.cuda(), dt, MASK_OWT, seed=seed,
+                                     offset=9, fast_math=fast, n_exact=n_exact)
+        assert torch.equal(xn.cpu(), ref), (float(t[0]), seed, fast)
+
+
+@pytest.mark.parametrize('from_logits', [False, True])
+def test_update_constructed_near_ties(ops, from_logits):
+  """Rows whose two best columns are built 0, +-1, +-2 fp32 ulps apart in q/g
+  (same random stream the kernel draws): the approximate pass cannot rank them,
+  the re-evaluation must, and exact ties must go to the first index.  fp32
+  inputs, so the construction is exact; t = 2 dt (mask-key prefilter active) and
+  t = dt / 2 (q_mask < 0: no prefilter)."""
+  R = 96
+  dt = (1 - 1e-5) / 1000
+  seed, off = 77, 3
+  u = ops.philox_uniform(R, V_OWT, seed, off).cpu()
+  eps = torch.tensor(1e-10, dtype=torch.float32)
+  g = eps - (u + eps).log()
+  ok = _exact_log_ok(u)
+  ok[:, MASK_OWT] = False
+  gs = torch.where(ok, g, torch.full_like(g, float('inf')))
+  two = gs.topk(2, dim=-1, largest=False)
+  a, b = two.indices[:, 0], two.indices[:, 1]
+  ga, gb = two.values[:, 0], two.values[:, 1]
+  rows = torch.arange(R)
+  x = torch.full((R, 1), MASK_OWT)
+  t = torch.where(rows % 2 == 0, torch.tensor(2 * dt), torch.tensor(0.5 * dt)).float()
+  kk = (rows // 2) % 5 - 2                      # ulp offsets -2..2
+  def bump(v, k):
+    for _ in range(2):
+      v = torch.where(k > 0, torch.nextafter(v, torch.full_like(v, float('inf'))), v)
+      v = torch.where(k < 0, torch.nextafter(v, torch.full_like(v, -float('inf'))), v)
+      k = k - k.sign()
+    return v
+  if from_logits:
+    logits = torch.full((R, V_OWT), -25.0) + torch.rand(R, V_OWT)
+    logits[rows, a] = 0.0
+    logits[rows, b] = bump((gb / ga).log(), kk)
+    dl = ops.alloc_logits(R, 1, V_OWT, torch.float32); dl.copy_(logits.view(R, 1, V_OWT))
+    lse = ops.subs_row_lse(dl, x.cuda(), MASK_OWT)
+    p_cpu = ops.subs_logprobs(dl, x.cuda(), MASK_OWT, as_probs=True).cpu()
+    run = lambda fast, nx: ops.subs_ddpm_update(dl, lse, x.cuda(), t.cuda(), dt, MASK_OWT,
+                                                seed=seed, offset=off, fast_math=fast, n_exact=nx)
+  else:
+    p = torch.full((R, V_OWT), 1e-12)
+    p[rows, a] = 0.2
+    p[rows, b] = bump(0.2 * gb / ga, kk)
+    dp = ops.alloc_logits(R, 1, V_OWT, torch.float32); dp.copy_(p.view(R, 1, V_OWT))
+    p_cpu = p.view(R, 1, V_OWT)
+    run = lambda fast, nx: ops.ddpm_cache_update(dp, x.cuda(), t.cuda(), dt, MASK_OWT,
+                                                 seed=seed, offset=off, fast_math=fast, n_exact=nx)
+  _, ref = orc.ddpm_caching_update(None, x, t, dt, u.view(R, 1, V_OWT), MASK_OWT,
+                                   p_x0=p_cpu.clone())
+  # the construction worked: the winner is one of the two columns, both occur,
+  # and the two keys are within a few ulps
+  assert bool(((ref[:, 0] == a) | (ref[:, 0] == b)).all())
+  assert (ref[:, 0] == a).any() and (ref[:, 0] == b).any()
+  nx = torch.zeros(1, dtype=torch.int64, device='cuda')
+  assert torch.equal(run(False, nx).cpu(), ref)
+  assert nx.item() == 0
+  assert torch.equal(run(True, nx).cpu(), ref)
+  assert nx.item() == R, nx.item()   # every such row took the re-evaluation
+
+
+def test_update_fast_equals_reference_kernel_full_size(ops):
+  """BASELINE configs[1] size (64 x 1024 rows x 50,258 columns, bf16 logits): the
+  fast path and the reference kernel emit identical tokens on the same stream,
+  early (dt/t ~ 1e-3), late (dt/t = 0.5) and at the last step (q_mask ~ 0)."""
+  torch.manual_seed(3)
+  B, L = 64, 1024
+  dl = ops.alloc_logits(B, L, V_OWT); dl.normal_(0, 2)
+  x = torch.full((B, L), MASK_OWT, dtype=torch.int64, device='cuda')
+  x[::3, ::5] = 7
+  lse = ops.subs_row_lse(dl, x, MASK_OWT)
+  dt = (1 - 1e-5) / 1000
+  nx = torch.zeros(1, dtype=torch.int64, device='cuda')
+  for i, t in enumerate((torch.linspace(1.0, 0.01, B), torch.full((B,), 2 * dt),
+                         torch.full((B,), dt + 1e-5))):
+    xf = ops.subs_ddpm_update(dl, lse, x, t.cuda(), dt, MASK_OWT, seed=5, offset=i,
+                              fast_math=True, n_exact=nx)
+    xe = ops.subs_ddpm_update(dl, lse, x, t.cuda(), dt, MASK_OWT, seed=5, offset=i)
+    assert torch.equal(xf, xe), i
+  assert 0 < nx.item() < 200   # near-ties exist at this size, and stay rare
 
 
 def test_update_unmasks_at_expected_rate(ops):
@@ -227,7 +368,9 @@ def test_update_unmasks_at_expected_rate(ops):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_fused_update_from_logits(ops, dtype):
-  """(a)+(b) fused: logits -> x_next equals oracle SUBS -> exp -> update."""
+  """(a)+(b) fused: logits -> x_next.  The kernel's p_x0 = expf(logit - lse) is
+  within 1e-5 (relative) of the oracle's SUBS -> exp, and given that p_x0 the
+  race is the oracle's, token for token (supplied u and in-kernel Philox)."""
   torch.manual_seed(9)
   B, L = 2, 6
   logits = (torch.randn(B, L, V_OWT) * 3).to(dtype)
@@ -237,23 +380,28 @@ def test_fused_update_from_logits(ops, dtype):
   dt = (1 - 1e-5) / 1000
   u = torch.rand(B, L, V_OWT)
   logp = orc.subs_parameterization(logits.float().clone(), x, MASK_OWT)
-  _, ref = orc.ddpm_caching_update(None, x, t, dt, u, MASK_OWT, p_x0=logp.exp())
   dl = ops.alloc_logits(B, L, V_OWT, dtype); dl.copy_(logits)
   lse = ops.subs_row_lse(dl, x.cuda(), MASK_OWT)
+  p_dev = ops.subs_logprobs(dl, x.cuda(), MASK_OWT, out_dtype=torch.float32,
+                            as_probs=True).cpu()
+  m = x == MASK_OWT
+  rel = (p_dev[m] - logp.exp()[m]).abs() / logp.exp()[m].clamp(min=1e-30)
+  assert rel[:, :MASK_OWT].max().item() <= 1e-5
+  _, ref = orc.ddpm_caching_update(None, x, t, dt, u, MASK_OWT, p_x0=p_dev.clone())
   xn = ops.subs_ddpm_update(dl, lse, x.cuda(), t.cuda(), dt, MASK_OWT, u=u.cuda())
-  tt = t.squeeze(-1)[:, None, None]
-  q = logp.exp() * (tt - (tt - dt)); q[:, :, MASK_OWT] = (tt - dt)[:, :, 0]
-  r = q / (1e-10 - (u + 1e-10).log())
-  assert _near_tie_only(r, xn.cpu(), ref)
+  assert torch.equal(xn.cpu(), ref)
   assert torch.equal(xn.cpu()[x != MASK_OWT], x[x != MASK_OWT])
-  # philox variant against oracle with the materialised draw
+  # the oracle's own p_x0 gives the same tokens on these rows (no near-tie among them)
+  _, ref2 = orc.ddpm_caching_update(None, x, t, dt, u, MASK_OWT, p_x0=logp.exp())
+  assert torch.equal(ref2, ref)
+  # philox variants against the oracle with the materialised draw
   up = ops.philox_uniform(B * L, V_OWT, 99, 5)
   _, refp = orc.ddpm_caching_update(None, x, t, dt, up.cpu().view(B, L, V_OWT),
-                                    MASK_OWT, p_x0=logp.exp())
-  xp = ops.subs_ddpm_update(dl, lse, x.cuda(), t.cuda(), dt, MASK_OWT, seed=99,
-                            offset=5)
-  rp = q / (1e-10 - (up.cpu().view(B, L, V_OWT) + 1e-10).log())
-  assert _near_tie_only(rp, xp.cpu(), refp)
+                                    MASK_OWT, p_x0=p_dev.clone())
+  for fast in (False, True):
+    xp = ops.subs_ddpm_update(dl, lse, x.cuda(), t.cuda(), dt, MASK_OWT, seed=99,
+                              offset=5, fast_math=fast)
+    assert torch.equal(xp.cpu(), refp), fast
 
 
 @pytest.mark.parametrize('fast', [False, True])
