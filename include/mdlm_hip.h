@@ -453,6 +453,21 @@ int mdlm_subs_nll_bwd(const void* logits, int64_t ld, int dtype,
 int mdlm_grad_sumsq(const float* g, int64_t n, float* partial_1024, float* out,
                     void* stream);
 
+/* mdlm_grad_sumsq without the workspace argument and without any allocation.
+ * NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot allocate
+ * or carry a workspace (code under HIP graph capture, tight serving / training
+ * loops, harnesses that forbid hipMalloc).  The 1024 partial sums live in a
+ * file-scope device array of the library (4 KiB per GPU, held until the process
+ * ends); the entry point calls no hipMalloc / hipFree / allocating routine.
+ * Same kernels, same summation order, hence bit-identical to mdlm_grad_sumsq.
+ * n > MDLM_SUMSQ_STATIC_MAX_N is rejected (-1, message).  The first call on a
+ * device looks the array's address up (hipGetSymbolAddress): make that call
+ * outside a graph capture.  All calls on one GPU share the array -- every call
+ * rewrites all of it, so consecutive calls are independent, but calls that
+ * OVERLAP on one GPU (two streams) race on it. */
+#define MDLM_SUMSQ_STATIC_MAX_N (1ll << 34)
+int mdlm_grad_sumsq_static(const float* g, int64_t n, float* out, void* stream);
+
 /* clip_grad_norm_ (configs/config.yaml:69) + torch.optim.AdamW step
  * (diffusion.py:449-459) + EMA (models/ema.py:44-49, diffusion.py:254-259) +
  * bf16 copy of the new weights, on flat buffers.  g is scaled by grad_scale

@@ -70,6 +70,7 @@ SIGNATURES = {
   'mdlm_gemm_tn_splitk': [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
   'mdlm_splitk_reduce': [_vp, _vp, _i64, _i32, _i64, _vp],
   'mdlm_grad_sumsq': [_vp, _i64, _vp, _vp, _vp],
+  'mdlm_grad_sumsq_static': [_vp, _i64, _vp, _vp],
   'mdlm_adamw_ema': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp, _f32, _f32, _vp],
   'mdlm_compact_active': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
 }

@@ -10,6 +10,7 @@
 // models/ema.py:29-49, configs/config.yaml:69 (gradient_clip_val 1.0).  The
 // reference gets every backward from torch autograd.
 #include "common.h"
+#include <mutex>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace mdlm {
@@ -787,6 +788,54 @@ extern "C" int mdlm_grad_sumsq(const float* g, int64_t n, float* partial_1024, f
   MDLM_CHECK_ARG(g && partial_1024 && out && n >= 0, "grad_sumsq: bad args");
   sumsq_partial_kernel<<<1024, 256, 0, ST(stream)>>>(g, n, partial_1024);
   sumsq_final_kernel<<<1, 256, 0, ST(stream)>>>(partial_1024, 1024, out);
+  MDLM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- the one entry point that allocates nothing AND needs no workspace ---------
+// Same two kernels as mdlm_grad_sumsq; the 1024 per-workgroup partial sums live in
+// a file-scope device array instead of a caller-supplied buffer, for callers that
+// cannot allocate (HIP graph capture, tight serving loops).  Each GPU holds its
+// own copy of the array at its own address for the life of the process (4 KiB).
+constexpr int SUMSQ_PARTIALS = 1024;
+constexpr int MDLM_MAX_DEVICES = 64;
+static __device__ __align__(256) float scratch[SUMSQ_PARTIALS];
+// Device address of `scratch` per GPU.  The array's NAME is only a host-side
+// stand-in in host code; kernels, memsets and copies must be given this pointer.
+static float* g_scratch_ptr[MDLM_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+static int scratch_for_current_device(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { set_error("grad_sumsq_static: hipGetDevice: %s", hipGetErrorString(e)); return (int)e; }
+  if (dev < 0 || dev >= MDLM_MAX_DEVICES) { set_error("grad_sumsq_static: device %d outside [0,%d)", dev, MDLM_MAX_DEVICES); return -1; }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {   // once per device, with that device current
+    float* p = nullptr;
+    e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+      set_error("grad_sumsq_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+      return e != hipSuccess ? (int)e : -1;
+    }
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+
+extern "C" int mdlm_grad_sumsq_static(const float* g, int64_t n, float* out, void* stream) {
+  MDLM_CHECK_ARG(g && out && n >= 0, "grad_sumsq_static: bad args");
+  MDLM_CHECK_ARG(n <= MDLM_SUMSQ_STATIC_MAX_N,
+                 "grad_sumsq_static: n = %lld exceeds the supported maximum of %lld elements; "
+                 "use mdlm_grad_sumsq with a caller-owned workspace",
+                 (long long)n, (long long)MDLM_SUMSQ_STATIC_MAX_N);
+  float* part = nullptr;
+  const int rc = scratch_for_current_device(&part);
+  if (rc != 0) return rc;
+  // every launch rewrites all 1024 partials, so nothing of the previous call survives
+  sumsq_partial_kernel<<<SUMSQ_PARTIALS, 256, 0, ST(stream)>>>(g, n, part);
+  sumsq_final_kernel<<<1, 256, 0, ST(stream)>>>(part, SUMSQ_PARTIALS, out);
   MDLM_LAUNCH_CHECK();
   return 0;
 }
