@@ -512,3 +512,63 @@ def test_checkpoint_ingestion(ops, tmp_path):
                  SyntheticTokenizer(vocab_size=V - 1, eos_token_id=7)).cuda()
   cli._load_backbone_weights(m3, st_path)
   assert torch.equal(m3.backbone(x, torch.zeros(4).cuda()), before)
+
+
+def test_full_size_configs1_backbone_and_fused_step(ops):
+  """BASELINE configs[1] at its real size, B = 1: DiT-small (12 blocks, D = 768,
+  12 heads), L = 1024, V = 50,258 (reference models/dit.py:359-370,
+  diffusion.py:592-610).  (1) 12-block logits against the fp32 oracle; (2) one
+  fused sampler step from a half-masked x: the masked-row gather, the tail on
+  the gathered rows, the 197th (82-column) vocabulary tile and the row scatter
+  into the cache give bit-identical logits to the plain forward; (3) the step's
+  tokens equal the oracle race on those logits and the same Philox uniforms."""
+  from mdlm_amd.config import load_config
+  from mdlm_amd.diffusion import Diffusion
+  from mdlm_amd.tokenizer import SyntheticTokenizer
+  Vf, Mf = 50258, 50257
+  cfg = load_config(['model=small', 'loader.eval_batch_size=1', 'sampling.steps=1000'])
+  model = Diffusion(cfg, SyntheticTokenizer(vocab_size=Vf - 1)).cuda()
+  m = cfg.model
+  p = orc.synthetic_dit_params(m.hidden_size, m.n_heads, m.n_blocks, m.cond_dim, Vf, seed=1)
+  sd = dict(p); sd['rotary_emb.inv_freq'] = model.backbone.rotary_emb.inv_freq
+  model.backbone.load_state_dict(sd)
+  model.ema = None
+  L = m.length
+  torch.manual_seed(4)
+  x = torch.randint(0, Vf - 1, (1, L))
+  x[torch.rand(1, L) < 0.5] = Mf
+  msk = (x == Mf)[0]
+  assert 400 < int(msk.sum()) < 620
+  # (1) backbone vs oracle
+  xc = x.cuda()
+  logits = model.backbone(xc, torch.zeros(1, device='cuda'))            # (1, L, V) bf16
+  with torch.no_grad():
+    ref = orc.dit_forward(p, x, torch.zeros(1), m.n_heads, m.n_blocks)   # fp32
+  got = logits.float().cpu()
+  rel = ((got - ref).norm() / ref.norm()).item()
+  assert rel < 2e-2, rel
+  # log-probs of the masked rows: bf16 logits of magnitude <= 16 carry <= 0.03 of
+  # rounding each, 12 blocks of bf16 GEMMs add to it: bound 0.25 absolute, 2e-2 rms
+  lp_got = torch.log_softmax(got[0, msk][:, :Mf], -1)
+  lp_ref = torch.log_softmax(ref[0, msk][:, :Mf], -1)
+  d = (lp_got - lp_ref).abs()
+  assert d.max().item() < 0.25 and d.pow(2).mean().sqrt().item() < 2e-2, (d.max().item(), d.pow(2).mean().sqrt().item())
+  # (2) one fused step (per-sample cache, masked rows only, tail on gathered rows)
+  st = model._sampler_state(1, L)
+  xa, xb = st['xa'], st['xb']
+  xa.copy_(xc); st['changed'].fill_(1); st['nfe'].zero_()
+  model.seed_rng(99)
+  t = torch.full((1,), 0.05, device='cuda')
+  dt = (1 - 1e-5) / 1000
+  model._fused_step(st, xa, xb, t, dt)
+  cache = st['cache']
+  assert torch.equal(cache[0][msk.cuda()], logits[0][msk.cuda()])
+  assert int(st['nfe'].item()) == 1
+  # (3) tokens vs the oracle race on the kernel's own fp32 p_x0 and the same uniforms
+  p_dev = ops.subs_logprobs(cache, xa, Mf, out_dtype=torch.float32, as_probs=True).cpu()
+  u = ops.philox_uniform(L, Vf, 99, 0).cpu().view(1, L, Vf)
+  _, xr = orc.ddpm_caching_update(None, x, t.cpu(), dt, u, Mf, p_x0=p_dev)
+  assert torch.equal(xb.cpu(), xr)
+  n_un = int((xr != x).sum())
+  assert 1 <= n_un <= 40 and int(st['changed'].item()) == 1
+  assert torch.equal(xr[x != Mf], x[x != Mf])
