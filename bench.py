@@ -8,11 +8,14 @@ A "step" is one full `restore_model_and_sample(num_steps=1000)` over one batch
 (BASELINE.json configs[1]: DiT-small 169M, L=1024, T=1000, batch 64/GPU, bf16
 operands, GPT-2-shaped vocab 50,258, seeded synthetic weights, all-mask prior).
 Ranks are independent replicas (seed + rank); no data-path collective.  Rank 0
-prints ONE JSON line: metric = ddpm_cache samples/sec (whole job), plus
-`roofline` for the dominant kernel (the gate/residual bf16 MFMA GEMM
-instantiation, timed live with HIP events on the launch stream; the vocab
-projection is reported beside it) and `cpu_baseline` (the CPU oracle timed on
-this box's host cores on a bounded sample).
+prints ONE JSON line: metric = ddpm_cache samples/sec (whole job).  The timed
+region carries no instrumentation; one more batch after it is profiled with
+HIP events on the launch stream around every kernel of every k-th denoising
+step, giving `rooflines` (every loop kernel: algorithmic flops or bytes / launch
+time / peak) and `roofline` (the dominant kernel by total time).  `cpu_baseline`
+is the CPU oracle timed on this box's host cores on a bounded sample; `dist`
+records the backend, the world size and an all-reduce check.
+`python bench.py --gpus N` without torchrun starts its own N ranks.
 
 Other workloads of BASELINE.json's config list, each printing its own JSON line
 (never the driver's default): `--workload train` (configs[4], LM1B training
@@ -228,9 +231,150 @@ def semi_ar_bench(args):
   mdist.barrier()
 
 
+def dist_block(world, dev):
+  """What proves the collectives saw N ranks: backend, world size and a SUM
+  all-reduce of (rank + 1) checked against N (N + 1) / 2 on every rank."""
+  import torch.distributed as tdist
+  if world == 1:
+    return {'backend': None, 'world_size': 1, 'allreduce_check': True}
+  t = torch.tensor([float(mdist.rank() + 1)], dtype=torch.float64, device=dev)
+  mdist.all_reduce_sums(t)
+  return {'backend': tdist.get_backend(), 'world_size': tdist.get_world_size(),
+          'allreduce_check': bool(t.item() == world * (world + 1) / 2)}
+
+
+def self_launch(args):
+  """`python bench.py --gpus N` without torchrun: the parent -- before anything
+  touches a GPU -- starts N fresh child processes (one rank per GPU) with
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, relays rank 0's JSON line and
+  returns the worst exit code.  A stalled child dumps its Python stacks and
+  exits non-zero by itself (faulthandler, armed in main())."""
+  import socket
+  import subprocess
+  n = args.gpus
+  if os.environ.get('MDLM_DIST_BACKEND', 'nccl') == 'nccl' and args.workload != 'dist_check':
+    have = torch.cuda.device_count()   # counting devices does not initialise HIP
+    if have < n:
+      raise SystemExit(f'--gpus {n}: {have} GPU(s) visible (one RCCL rank per GPU; '
+                       'MDLM_DIST_BACKEND=gloo rehearses N ranks on fewer cards)')
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  procs = []
+  for r in range(n):
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+               LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    procs.append(subprocess.Popen(
+      [sys.executable, '-u', os.path.abspath(__file__)] + sys.argv[1:], env=env,
+      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+  rc = 0
+  try:
+    for line in procs[0].stdout:     # rank 0 prints the one JSON line
+      sys.stdout.write(line)
+      sys.stdout.flush()
+    for p in procs:
+      rc = max(rc, abs(p.wait()))
+  finally:
+    for p in procs:                  # exact PIDs of our own children only
+      if p.poll() is None:
+        p.terminate()
+  return rc
+
+
+def dist_check_bench(args):
+  """Launcher + collective rehearsal without compute (runs on CPU over gloo as
+  well): init, barrier, all-reduce check, max-over-ranks; one JSON line."""
+  rank, local_rank, world = mdist.init()
+  dev = torch.device('cpu')
+  if torch.cuda.is_available():
+    torch.cuda.set_device(mdist.local_device(local_rank))
+    dev = torch.device('cuda', mdist.local_device(local_rank))
+  mdist.barrier()
+  t0 = time.perf_counter()
+  d = dist_block(world, dev)
+  el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+  if rank == 0:
+    print(json.dumps({'metric': 'dist_check', 'n_gpus': world, 'dist': d,
+                      'allreduce_s': round(el, 6)}), flush=True)
+  mdist.barrier()
+  if not d['allreduce_check']:
+    raise SystemExit(3)
+
+
+# per-kernel roofline bookkeeping of the sampling loop: tag -> (kernel symbol, bound)
+KERNELS = {
+  'gemm_out': ('gemm_bf16_kernel<EPI_GATE_RESIDUAL,fp32> attn_out 768->768', 'mfma'),
+  'gemm_fc2': ('gemm_bf16_kernel<EPI_GATE_RESIDUAL,fp32> mlp.2 3072->768', 'mfma'),
+  'gemm_fc1': ('gemm_bf16_kernel<EPI_BIAS_GELU,bf16> mlp.0 768->3072', 'mfma'),
+  'gemm_qkv': ('gemm_bf16_kernel<EPI_QKV_ROTARY,bf16> 768->2304 + rotary', 'mfma'),
+  'gemm_vocab': ('gemm_bf16_kernel<EPI_STORE,bf16> vocab projection 768->V, masked rows', 'mfma'),
+  'attention': ('attn_fwd_kernel', 'mfma'),
+  'update': ('ddpm_update_fast_kernel (SUBS + race fused from logits)', 'hbm'),
+  'ln_modulate': ('ln_modulate_kernel', 'hbm'),
+  'embed': ('embed_rows_kernel', 'hbm'),
+  'gather_rows': ('gather_rows_kernel', 'hbm'),
+  'row_lists': ('compact_active_kernel + masked_row_map_kernel', 'launch'),
+  'gemm_gate_residual': ('gemm_bf16_kernel<EPI_GATE_RESIDUAL,fp32,256x256> (attn_out 768->768 and '
+                         'mlp.2 3072->768: one symbol in the rocprof trace)', 'mfma'),
+}
+# tag -> key of profiles/pmc_traffic.json (tools/pmc_traffic.py)
+PMC_TAGS = {'gemm_gate_residual': 'gate_residual', 'gemm_fc1': 'mlp_up_gelu',
+            'gemm_qkv': 'qkv_rotary', 'gemm_vocab': 'vocab', 'attention': 'attention',
+            'update': 'ddpm_update', 'ln_modulate': 'ln_modulate'}
+
+
+def kernel_rooflines(events, traffic):
+  """tag -> roofline dict from the HIP-event pairs of the profiling batch:
+  achieved = sum(algorithmic work) / sum(launch time)."""
+  vals = {}
+
+  def rows_of(r):
+    if torch.is_tensor(r):
+      k = (r.data_ptr(), r._version)
+      if k not in vals:
+        vals[k] = int(r)
+      return vals[k]
+    return r
+  out = {}
+  events = dict(events)
+  # one kernel symbol in a rocprof trace: both gate/residual GEMM shapes together
+  events['gemm_gate_residual'] = events.get('gemm_out', []) + events.get('gemm_fc2', [])
+  for tag, evs in events.items():
+    if not evs:
+      continue
+    ms = [s.elapsed_time(e) for s, e, _, _ in evs]
+    n = max(1, len(ms))
+    rows = [rows_of(r) for _, _, r, _ in evs]
+    work = sum(w * r for (_, _, _, w), r in zip(evs, rows))
+    t = sum(ms) * 1e-3
+    kernel, bound = KERNELS.get(tag, (tag, 'hbm'))
+    d = {'tag': tag, 'kernel': kernel, 'bound': bound, 'launches': len(ms),
+         'avg_launch_ms': round(sum(ms) / n, 4), 'total_ms': round(sum(ms), 2),
+         'avg_rows_per_launch': round(sum(rows) / n, 1)}
+    if bound == 'mfma':
+      ach = work / t / 1e12 if t > 0 else 0.0
+      d.update(achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
+               frac=round(ach / PEAK_BF16_TFLOPS, 4),
+               algorithmic_gflop_per_launch=round(work / n / 1e9, 2))
+    elif bound == 'hbm':
+      ach = work / t / 1e9 if t > 0 else 0.0
+      d.update(achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+               frac=round(ach / PEAK_HBM_GBS, 4),
+               algorithmic_mbytes_per_launch=round(work / n / 1e6, 2))
+    tr = traffic.get(PMC_TAGS.get(tag))
+    d['traffic'] = (round(tr['hbm_bytes_per_launch'] / traffic['_rows_per_launch_profiled']
+                          * sum(rows) / n) if tr else None)
+    if tr:
+      d['traffic_unit'] = ('HBM bytes/launch: PMC FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 '
+                           '--pmc passes (profiles/pmc_traffic.json), scaled by live rows')
+    out[tag] = d
+  return out
+
+
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--workload', default='sample', choices=['sample', 'train', 'semi_ar'])
+  ap.add_argument('--workload', default='sample',
+                  choices=['sample', 'train', 'semi_ar', 'dist_check'])
   ap.add_argument('--global-batch', type=int, default=512)
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=2)
@@ -239,13 +383,26 @@ def main():
   ap.add_argument('--T', type=int, default=1000)
   ap.add_argument('--model', default='small')
   ap.add_argument('--cache-policy', default='sample', choices=['sample', 'batch', 'none'])
+  ap.add_argument('--race', default='fast', choices=['fast', 'reference'],
+                  help='fast: approximate ranking + exact re-evaluation of near-ties; '
+                       'reference: every element in the defining arithmetic.  Same tokens.')
+  ap.add_argument('--profile-stride', type=int, default=8,
+                  help='profiling batch (after the timed region): HIP events around '
+                       'every kernel of each k-th denoising step; 0 = skip')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-policy-compare', action='store_true')
   ap.add_argument('--no-eval', action='store_true')
   args = ap.parse_args()
-  if os.environ.get('MDLM_FAULT_DUMP_S'):   # debugging aid: Python stacks of a stuck rank
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    raise SystemExit(self_launch(args))
+  world_env = int(os.environ.get('WORLD_SIZE', 1))
+  # a stuck rank dumps its Python stacks and exits non-zero (always armed for N > 1)
+  dump_s = os.environ.get('MDLM_FAULT_DUMP_S') or ('1500' if world_env > 1 else '')
+  if dump_s:
     import faulthandler
-    faulthandler.dump_traceback_later(int(os.environ['MDLM_FAULT_DUMP_S']), exit=True)
+    faulthandler.dump_traceback_later(int(dump_s), exit=True)
+  if args.workload == 'dist_check':
+    return dist_check_bench(args)
   if args.workload == 'train':
     return train_bench(args)
   if args.workload == 'semi_ar':
@@ -253,85 +410,63 @@ def main():
 
   rank, local_rank, world = mdist.init()
   if world != args.gpus:
-    if args.gpus > 1:
-      raise SystemExit(f'--gpus {args.gpus} needs torchrun with {args.gpus} ranks '
-                       f'(WORLD_SIZE={world})')
+    raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
   torch.cuda.set_device(mdist.local_device(local_rank))
   dev = torch.device('cuda', mdist.local_device(local_rank))
 
+  fast = args.race == 'fast'
   cfg = load_config([f'model={args.model}', f'loader.eval_batch_size={args.batch}',
                      f'sampling.steps={args.T}', f'sampling.cache_policy={args.cache_policy}',
-                     'sampling.fast_math=true', f'trainer.devices={world}'])
+                     f'sampling.fast_math={str(fast).lower()}', f'trainer.devices={world}'])
   model = build_model(cfg, seed=1)
   model.seed_rng(mdist.rank_seed(cfg.seed, rank))
   B, L, V = args.batch, cfg.model.length, model.vocab_size
+  D, nb = cfg.model.hidden_size, cfg.model.n_blocks
   bb = model.backbone
-  bb.profile_events = None
 
   def sync_all():
     torch.cuda.synchronize()
     mdist.barrier()
     torch.cuda.synchronize()
 
+  dist_info = dist_block(world, dev)
   for _ in range(args.warmup):
     model.restore_model_and_sample(num_steps=args.T)
   sync_all()
-  # live HIP-event timing of the two heaviest GEMM instantiations
-  bb.profile_events = {'gate_residual': [], 'vocab': []}
+  # ---- timed region: no instrumentation of any kind ---------------------------
   t0 = time.perf_counter()
   for _ in range(args.steps):
     model.restore_model_and_sample(num_steps=args.T)
-  torch.cuda.synchronize()
-  mdist.barrier()
-  torch.cuda.synchronize()
+  sync_all()
   elapsed = time.perf_counter() - t0
   elapsed = mdist.max_over_ranks(elapsed, dev)
-  events = bb.profile_events
-  bb.profile_events = None
   nfe_last = int(model.last_nfe.item())
+  n_exact = int(model.last_n_exact.item())
 
-  # ---- roofline: algorithmic flops / launch time, from the live events ------
-  traffic = {}
-  tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-  if os.path.exists(tpath):   # HBM bytes per launch from separate rocprofv3 --pmc passes
-    traffic = json.load(open(tpath))
-
-  def _traffic(tag, rows):
-    t = traffic.get(tag)
-    if not t:
-      return None
-    return round(t['hbm_bytes_per_launch'] / traffic.get('_rows_per_launch_profiled', 65536) * rows)
-
-  def roof(tag, kernel):
-    evs = events[tag]
-    ms = [s.elapsed_time(e) for s, e, _, _ in evs]
-    cache = {}
-    flops = 0.0
-    rows_sum = 0
-    for _, _, r, fpr in evs:
-      if torch.is_tensor(r):
-        k = r.data_ptr()
-        if k not in cache:
-          cache[k] = int(r)
-        r = cache[k]
-      flops += fpr * r
-      rows_sum += r
-    n = len(ms)
-    t = sum(ms) * 1e-3
-    ach = flops / t / 1e12 if t > 0 else 0.0
-    return {'kernel': kernel, 'bound': 'mfma', 'achieved': round(ach, 1),
-            'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-            'traffic': _traffic(tag, rows_sum / max(1, n)),
-            'traffic_unit': 'HBM bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json, scaled by rows)',
-            'launches': n, 'avg_launch_ms': round(sum(ms) / max(1, n), 4),
-            'avg_rows_per_launch': round(rows_sum / max(1, n), 1),
-            'algorithmic_gflop_per_launch': round(flops / max(1, n) / 1e9, 2)}
-  # dominant kernel by total time (profiles/r01_*_kernel_stats.csv): the
-  # gate/residual GEMM instantiation (out-projection K=768 and MLP-down K=3072)
-  roofline = roof('gate_residual',
-                  'gemm_bf16_kernel<EPI_GATE_RESIDUAL,fp32,256x256> (attn_out 768->768 and mlp.2 3072->768)')
-  roofline_vocab = roof('vocab', 'gemm_bf16_kernel<EPI_STORE,bf16,256x256> (vocab projection 768->50258, masked rows)')
+  # ---- profiling batch (outside the timed region): HIP events on the launch
+  # stream around every kernel of each k-th step, live row counts of every step
+  rooflines, executed = {}, None
+  if args.profile_stride > 0:
+    traffic = {}
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tpath):   # HBM bytes per launch from separate rocprofv3 --pmc passes
+      traffic = json.load(open(tpath))
+    bb.profile_events = {}
+    model._profile = dict(stride=args.profile_stride, rows=[])
+    model.restore_model_and_sample(num_steps=args.T)
+    torch.cuda.synchronize()
+    events, rows = bb.profile_events, model._profile['rows']
+    bb.profile_events, model._profile = None, None
+    rooflines = kernel_rooflines(events, traffic)
+    # executed flops: full-width blocks on the active rows; the last block's tail
+    # and the vocabulary projection on the masked rows only
+    n_rows = sum(int(a) for a, _ in rows)
+    n_mrows = sum(int(b) for _, b in rows)
+    f_head = 2.0 * D * 3 * D + 4.0 * L * D            # QKV + attention, per row
+    f_tail = 2.0 * D * D + 16.0 * D * D                # out-proj + MLP, per row
+    nfe_prof = int(model.last_nfe.item())
+    executed = ((nb - 1) * (f_head + f_tail) * n_rows + f_head * n_rows
+                + (f_tail + 2.0 * D * V) * n_mrows) * (nfe_last / max(1, nfe_prof))
 
   samples = world * B * args.steps
   value = samples / elapsed
@@ -344,15 +479,35 @@ def main():
     'dtype': 'bf16', 'data': 'synthetic',
     'config': {'workload': (f'mdlm-owt DiT-small ddpm_cache sampling, L={L}, T={args.T}, '
                             f'batch={B}/GPU, bf16, V={V}, noise_removal'),
-               'cache_policy': args.cache_policy, 'rng': 'in-kernel Philox4x32-10',
+               'cache_policy': args.cache_policy,
+               'race': ('bit-exact; approximate ranking + exact re-evaluation of near-ties '
+                        '(sampling.fast_math=true, the default)' if fast else
+                        'bit-exact; every element in the defining arithmetic '
+                        '(sampling.fast_math=false)'),
+               'rng': 'in-kernel Philox4x32-7',
                'parallelism': f'replicas x{world}'},
+    'dist': dist_info,
     'nfe_per_sample': round(nfe_last / B, 1),
+    'race_rows_re_evaluated_exactly': n_exact,
     'ms_per_denoise_step': round(elapsed / args.steps / (args.T + 1) * 1e3, 3),
-    'roofline': roofline,
-    'roofline_vocab_gemm': roofline_vocab,
   }
-  out['backbone_tflops'] = round(
-    (nfe_last * 291.65e9 * args.steps) / elapsed / 1e12, 1)
+  if rooflines:
+    # dominant kernel = largest total time in the profiling batch
+    # (by kernel symbol: the two gate/residual shapes count as one kernel)
+    dom = max((d for t, d in rooflines.items()
+               if d['bound'] != 'launch' and t not in ('gemm_out', 'gemm_fc2')),
+              key=lambda d: d['total_ms'])
+    out['roofline'] = dom
+    out['rooflines'] = sorted((d for t, d in rooflines.items() if t != 'gemm_gate_residual'),
+                              key=lambda d: -d['total_ms'])
+    out['profile'] = {'stride': args.profile_stride,
+                      'note': ('separate batch after the timed region; HIP events on the launch '
+                               'stream around every kernel launch of each k-th denoising step')}
+  # model flops charge every sample-forward 291.65 GFLOP; executed
+  # flops count the vocabulary projection and the last block's tail on masked rows only
+  out['model_tflops'] = round((nfe_last * 291.65e9 * args.steps) / elapsed / 1e12, 1)
+  if executed is not None:
+    out['executed_tflops'] = round(executed * args.steps / elapsed / 1e12, 1)
 
   if not args.no_eval:
     # second half of the metric: NELBO eval tokens/s (q_xt + backbone + fused

@@ -126,6 +126,10 @@ class Diffusion(_Base):
     self._state = None
     self._eval_state = None
     self.last_nfe = None
+    # bench.py's profiling pass (outside its timed region): dict(stride=k,
+    # rows=[]) -> HIP events around every kernel of each k-th step, live row
+    # counts of every step
+    self._profile = None
 
   # ---------------------------------------------------------------- helpers
   def _validate_configuration(self):  # diffusion.py:155-166
@@ -334,7 +338,9 @@ class Diffusion(_Base):
       nfe=torch.zeros(1, dtype=torch.int64, device=dev),
       gather=torch.zeros(B * Lq + 256, **i32), scatter=torch.zeros(B * Lq + 256, **i32),
       n_mrows=torch.zeros(1, **i32), fresh=torch.ones(B, **i32),
-      zeros=torch.zeros(B, dtype=torch.float32, device=dev))
+      zeros=torch.zeros(B, dtype=torch.float32, device=dev),
+      # rows the fast race re-evaluated in the defining arithmetic (diagnostic)
+      n_exact=torch.zeros(1, dtype=torch.int64, device=dev))
     if lazy:
       if (B * Lq) % 256:
         raise NotImplementedError('sampling.lazy_unmask needs batch * length % 256 == 0')
@@ -354,15 +360,20 @@ class Diffusion(_Base):
                   self.config.sampling.get('cache_policy', 'sample') != 'none')
     if per_sample:
       aon = self.config.sampling.get('cache_policy', 'sample') == 'batch'
-      ops.compact_active(st['changed'], st['active'], st['n_active'],
-                         st['n_rows'], Lq, all_or_nothing=aon,
-                         nfe_accum=st['nfe'], fresh=st['fresh'])
+      timed = self.backbone._timed
+      timed('row_lists', 0, 0.0, lambda: ops.compact_active(
+        st['changed'], st['active'], st['n_active'], st['n_rows'], Lq,
+        all_or_nothing=aon, nfe_accum=st['nfe'], fresh=st['fresh']))
       row_map = None
       if self.config.sampling.get('masked_rows_only', True) and (B * Lq) % 256 == 0:
         # only masked rows need logits: carry-over / SUBS ignore the others
-        ops.masked_row_map(x, st['active'], st['n_active'], Lq, self.mask_index,
-                           st['gather'], st['scatter'], st['n_mrows'])
+        timed('row_lists', 0, 0.0, lambda: ops.masked_row_map(
+          x, st['active'], st['n_active'], Lq, self.mask_index, st['gather'],
+          st['scatter'], st['n_mrows']))
         row_map = (st['gather'], st['scatter'], st['n_mrows'])
+      if self._profile is not None:
+        self._profile['rows'].append((st['n_rows'].clone(), st['n_mrows'].clone()
+                                      if row_map is not None else st['n_rows'].clone()))
       self.backbone.run(x, st['zeros'], st['cache'], sigma_is_zero=True,
                         active=st['active'], n_active_dev=st['n_active'],
                         n_rows_dev=st['n_rows'], n_max=B, row_map=row_map)
@@ -383,10 +394,15 @@ class Diffusion(_Base):
     self._refresh_cache(st, x, sigma)
     B, Lq = st['B'], st['L']
     seed, off = self._draw(B * Lq * ((self.vocab_size + 3) // 4))
-    ops.subs_ddpm_update(
+    bb = self.backbone
+    n_masked = ((x == self.mask_index).sum()
+                if bb.profile_events is not None and bb.profile_sample else 0)
+    # algorithmic bytes of the update: masked rows x V bf16 logits
+    bb._timed('update', n_masked, 2.0 * self.vocab_size, lambda: ops.subs_ddpm_update(
       st['cache'], st['lse'], x, t_vec, dt, self.mask_index, seed=seed,
       offset=off, changed=st['changed'], x_next=x_next, fresh=st['fresh'],
-      fast_math=bool(self.config.sampling.get('fast_math', False)))
+      fast_math=bool(self.config.sampling.get('fast_math', False)),
+      n_exact=st['n_exact']))
 
   # ---- opt-in two-stage step (sampling.lazy_unmask=true) ---------------------
   def _lazy_refresh_hidden(self, st, x):
@@ -439,13 +455,17 @@ class Diffusion(_Base):
     x.fill_(self.mask_index)
     st['changed'].fill_(1)
     st['nfe'].zero_()
+    st['n_exact'].zero_()
     # t = timesteps[i] * ones(B, 1)  (diffusion.py:675-676), all steps at once
     t_all = timesteps[:, None].expand(num_steps + 1, B).contiguous()
     lazy = bool(self.config.sampling.get('lazy_unmask', False))
     if lazy and self.time_conditioning:
       raise NotImplementedError('sampling.lazy_unmask needs time_conditioning=False '
                                 '(the hidden-state cache is sigma-independent)')
+    prof = self._profile
     for i in range(num_steps):
+      if prof is not None:
+        self.backbone.profile_sample = i % prof['stride'] == 0
       if lazy:
         self._lazy_step(st, x, x_next, t_all[i], dt)
       else:
@@ -467,7 +487,9 @@ class Diffusion(_Base):
       self._refresh_cache(st, x, sigma)
       ops.subs_argmax(st['cache'], x, self.mask_index, out=x_next)
       x = x_next
+    self.backbone.profile_sample = False
     self.last_nfe = st['nfe']  # device counter; .item() syncs
+    self.last_n_exact = st['n_exact']
     return x.clone()
 
   def _sample_uncached(self, B, Lq, num_steps, timesteps, dt):

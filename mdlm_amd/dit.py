@@ -111,7 +111,8 @@ class DIT(nn.Module):
     self.output_layer = DDitFinalLayer(self.hidden, vocab_size, self.cond_dim)
     self.scale_by_sigma = _cfg(config, 'scale_by_sigma')
     self._prep = None   # device-side kernel operands (bf16 weights, tables)
-    self.profile_events = None
+    self.profile_events = None   # bench.py profiling pass only (see _timed)
+    self.profile_sample = False
     self._ws = None     # activation workspace
 
   # ------------------------------------------------------------ preparation
@@ -215,18 +216,20 @@ class DIT(nn.Module):
     return self._conditioning(p, sigma), sigma.shape[0]
 
   # ------------------------------------------------------------------ forward
-  def _timed(self, tag, rows, flops_per_row, fn):
-    """bench.py hook: HIP events on the launch stream around one kernel launch
-    (`profile_events` is a dict tag -> list of (start, end, rows, flops/row))."""
+  def _timed(self, tag, rows, work_per_row, fn):
+    """Profiling hook (bench.py, outside its timed region): HIP events on the
+    launch stream around one kernel launch.  `profile_events` is a dict tag ->
+    list of (start, end, rows, work/row) -- flops for the MFMA kernels, bytes
+    for the HBM-bound ones; `rows` may be a device counter (cloned)."""
     ev = self.profile_events
-    if ev is None or tag not in ev:
+    if ev is None or not self.profile_sample:
       return fn()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     fn()
     e1.record()
-    ev[tag].append((e0, e1, rows, flops_per_row))
+    ev.setdefault(tag, []).append((e0, e1, rows, work_per_row))
 
   def run(self, indices, sigma, logits_out, sigma_is_zero=False, active=None,
           n_active_dev=None, n_rows_dev=None, n_max=None, row_map=None,
@@ -255,15 +258,18 @@ class DIT(nn.Module):
       raise RuntimeError('active-sample compaction needs batch-invariant '
                          'conditioning (time_conditioning=False)')
     ld6, ld2 = 6 * D, 2 * D
-    ops.embed_rows(p['embed'], indices, x, sample_map=active, L=L,
-                   n_rows_dev=n_rows_dev)
+    prof = self.profile_events is not None and self.profile_sample
+    rows_t = None
+    if prof:  # one device copy of the live row count per forward
+      rows_t = n_rows_dev.clone() if n_rows_dev is not None else M
+    T = self._timed
+    V = self.vocab_size
+    LN_B, GEMM = 6.0 * D, 2.0 * D   # bytes per LN row; flops per row per output column
+    T('embed', rows_t, 4.0 * D + 8, lambda: ops.embed_rows(
+      p['embed'], indices, x, sample_map=active, L=L, n_rows_dev=n_rows_dev))
     q_ = qkv[:M * D]
     k_ = qkv[M * D:2 * M * D]
     vt_ = qkv[2 * M * D:3 * M * D]
-    ev = self.profile_events
-    rows_t = None
-    if ev is not None:  # one host copy of the live row count per forward
-      rows_t = n_rows_dev.clone() if n_rows_dev is not None else M
     # With a row map (only the masked rows' logits are read) the last block
     # stops being full-width after its attention: out-projection, MLP and the
     # final layer are row-wise, so they run on the gathered masked rows only.
@@ -273,45 +279,47 @@ class DIT(nn.Module):
     for bi, (bp, mod) in enumerate(zip(p['blocks'], mods)):
       # chunk order dit.py:249-250: shift_msa, scale_msa, gate_msa, shift_mlp,
       # scale_mlp, gate_mlp
-      ops.ln_modulate(x, bp['n1'], mod[:, 0:D], mod[:, D:2 * D], h, L, n_mod,
-                      ld6, n_rows_dev)
-      ops.gemm_bf16(h, bp['qkv'], qkv, EPI_QKV_ROTARY, rows_per_mod=L,
-                    rot_cos=p['cos'], rot_sin=p['sin'], n_heads=H,
-                    m_rows_dev=n_rows_dev, ldc=0, M=M)
-      ops.attn_fwd(q_, k_, vt_, ao, n_seq, H, L, n_seq_dev=n_active_dev)
+      T('ln_modulate', rows_t, LN_B, lambda: ops.ln_modulate(
+        x, bp['n1'], mod[:, 0:D], mod[:, D:2 * D], h, L, n_mod, ld6, n_rows_dev))
+      T('gemm_qkv', rows_t, GEMM * 3 * D, lambda: ops.gemm_bf16(
+        h, bp['qkv'], qkv, EPI_QKV_ROTARY, rows_per_mod=L, rot_cos=p['cos'],
+        rot_sin=p['sin'], n_heads=H, m_rows_dev=n_rows_dev, ldc=0, M=M))
+      T('attention', rows_t, 4.0 * L * D, lambda: ops.attn_fwd(
+        q_, k_, vt_, ao, n_seq, H, L, n_seq_dev=n_active_dev))
       if tail_rows and bi == n_blocks - 1:
         gather, scatter, live = row_map
         xm, aom = ws['xm'][:M], ws['aom'][:M]
-        ops.gather_rows(x, xm, ao, aom, gather, n_rows_dev=live, rows=M)
-        lt = live.clone() if ev is not None else None
-        self._timed('gate_residual', lt, 2.0 * D * D, lambda: ops.gemm_bf16(
+        lt = live.clone() if prof else None
+        T('gather_rows', lt, 12.0 * D, lambda: ops.gather_rows(
+          x, xm, ao, aom, gather, n_rows_dev=live, rows=M))
+        T('gemm_out', lt, GEMM * D, lambda: ops.gemm_bf16(
           aom, bp['out'], xm, EPI_GATE_RESIDUAL, gate=mod[:, 2 * D:3 * D],
           residual=xm, rows_per_mod=L, n_mod=1, mod_ld=ld6, m_rows_dev=live, M=M))
-        ops.ln_modulate(xm, bp['n2'], mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D], h,
-                        L, 1, ld6, live)
-        ops.gemm_bf16(h, bp['fc1'], mh, EPI_BIAS_GELU, bias=bp['b1'],
-                      m_rows_dev=live, M=M)
-        self._timed('gate_residual', lt, 2.0 * D * 4 * D, lambda: ops.gemm_bf16(
+        T('ln_modulate', lt, LN_B, lambda: ops.ln_modulate(
+          xm, bp['n2'], mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D], h, L, 1, ld6, live))
+        T('gemm_fc1', lt, GEMM * 4 * D, lambda: ops.gemm_bf16(
+          h, bp['fc1'], mh, EPI_BIAS_GELU, bias=bp['b1'], m_rows_dev=live, M=M))
+        T('gemm_fc2', lt, GEMM * 4 * D, lambda: ops.gemm_bf16(
           mh, bp['fc2'], xm, EPI_GATE_RESIDUAL, bias=bp['b2'],
           gate=mod[:, 5 * D:6 * D], residual=xm, rows_per_mod=L, n_mod=1,
           mod_ld=ld6, m_rows_dev=live, M=M))
         fm = mods[-1]
-        V = self.vocab_size
-        ops.ln_modulate(xm, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, 1,
-                        ld2, live)
-        self._timed('vocab', lt, 2.0 * V * D, lambda: ops.gemm_bf16(
+        T('ln_modulate', lt, LN_B, lambda: ops.ln_modulate(
+          xm, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, 1, ld2, live))
+        T('gemm_vocab', lt, GEMM * V, lambda: ops.gemm_bf16(
           h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
           m_rows_dev=live, out_row_map=scatter, ldc=logits_out.stride(-2), M=M))
         return logits_out
-      self._timed('gate_residual', rows_t, 2.0 * D * D, lambda: ops.gemm_bf16(
+      T('gemm_out', rows_t, GEMM * D, lambda: ops.gemm_bf16(
         ao, bp['out'], x, EPI_GATE_RESIDUAL, gate=mod[:, 2 * D:3 * D],
         residual=x, rows_per_mod=L, n_mod=n_mod, mod_ld=ld6,
         m_rows_dev=n_rows_dev, M=M))
-      ops.ln_modulate(x, bp['n2'], mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D], h,
-                      L, n_mod, ld6, n_rows_dev)
-      ops.gemm_bf16(h, bp['fc1'], mh, EPI_BIAS_GELU, bias=bp['b1'],
-                    m_rows_dev=n_rows_dev, M=M)
-      self._timed('gate_residual', rows_t, 2.0 * D * 4 * D, lambda: ops.gemm_bf16(
+      T('ln_modulate', rows_t, LN_B, lambda: ops.ln_modulate(
+        x, bp['n2'], mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D], h, L, n_mod, ld6,
+        n_rows_dev))
+      T('gemm_fc1', rows_t, GEMM * 4 * D, lambda: ops.gemm_bf16(
+        h, bp['fc1'], mh, EPI_BIAS_GELU, bias=bp['b1'], m_rows_dev=n_rows_dev, M=M))
+      T('gemm_fc2', rows_t, GEMM * 4 * D, lambda: ops.gemm_bf16(
         mh, bp['fc2'], x, EPI_GATE_RESIDUAL, bias=bp['b2'],
         gate=mod[:, 5 * D:6 * D], residual=x, rows_per_mod=L,
         n_mod=n_mod, mod_ld=ld6, m_rows_dev=n_rows_dev, M=M))
@@ -320,20 +328,19 @@ class DIT(nn.Module):
       return None
     fm = mods[-1]
     assert logits_out.shape[-1] == self.vocab_size
-    V = self.vocab_size
     if row_map is not None:
       gather, scatter, live = row_map
-      ops.ln_modulate(x, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod,
-                      ld2, n_rows_dev=live, row_gather=gather, rows=M)
-      self._timed('vocab', live.clone() if ev is not None else None, 2.0 * V * D,
-                  lambda: ops.gemm_bf16(
-                    h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
-                    m_rows_dev=live, out_row_map=scatter,
-                    ldc=logits_out.stride(-2), M=M))
+      lt = live.clone() if prof else None
+      T('ln_modulate', lt, LN_B, lambda: ops.ln_modulate(
+        x, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod, ld2,
+        n_rows_dev=live, row_gather=gather, rows=M))
+      T('gemm_vocab', lt, GEMM * V, lambda: ops.gemm_bf16(
+        h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
+        m_rows_dev=live, out_row_map=scatter, ldc=logits_out.stride(-2), M=M))
     else:
-      ops.ln_modulate(x, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod,
-                      ld2, n_rows_dev)
-      self._timed('vocab', rows_t, 2.0 * V * D, lambda: ops.gemm_bf16(
+      T('ln_modulate', rows_t, LN_B, lambda: ops.ln_modulate(
+        x, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod, ld2, n_rows_dev))
+      T('gemm_vocab', rows_t, GEMM * V, lambda: ops.gemm_bf16(
         h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
         rows_per_mod=L, m_rows_dev=n_rows_dev, out_sample_map=active,
         ldc=logits_out.stride(-2), M=M))

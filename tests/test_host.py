@@ -264,3 +264,23 @@ def test_gloo_world_size_2(tmp_path):
   res = json.loads(outs[0][0].strip().splitlines()[-1])
   assert res['ok'] and res['ddp_ok'] and res['max'] == 2.0 and res['seeds'] == [1, 2]
   assert res['gathered'] == [[0, 1, 2, 3], [10, 11, 12, 13]]
+
+
+def test_bench_self_launch_two_gloo_ranks():
+  """`python bench.py --gpus 2` without torchrun starts its own ranks (one child
+  process each, RANK / WORLD_SIZE / MASTER_* set by the parent) and relays rank
+  0's single JSON line; here over gloo on the CPU with the collective-only
+  workload (reference launcher: main.py:137-145; metric sync diffusion.py:380-383)."""
+  import json
+  import subprocess
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+  env['MDLM_DIST_BACKEND'] = 'gloo'
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+                      '--workload', 'dist_check'], env=env, capture_output=True,
+                     text=True, timeout=300)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1
+  d = json.loads(lines[0])['dist']
+  assert d == {'backend': 'gloo', 'world_size': 2, 'allreduce_check': True}
