@@ -270,22 +270,17 @@ int mdlm_ln_modulate(const float* x, const float* ln_w, const float* shift,
  *                    vt[b,h,64,l]; C = base of a buffer of 3*M*H*64 bf16
  *                    (q | k | vt).  rows_per_mod = L.
  * m_rows_dev: optional device int32 with the number of live rows (tiles
- * beyond it exit), so a fixed launch can serve a device-side active count. */
+ * beyond it exit), so a fixed launch can serve a device-side active count.
+ * tile: 0 = choose (256x256 when M % 256 == 0 and N >= 256, else 128x128),
+ * 1 = 128x128 always -- per call, so both configurations can be parity-tested on
+ * any shape; the library holds no tuning state. */
 int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
                    void* C, int64_t ldc, int dtype_c, int64_t M, int N, int K,
                    int epilogue, const float* gate, const float* residual,
                    int64_t rows_per_mod, int n_mod, int64_t mod_ld,
                    const float* rot_cos, const float* rot_sin, int n_heads,
                    const int32_t* m_rows_dev, const int32_t* out_sample_map,
-                   const int32_t* out_row_map, void* stream);
-
-/* Test hook, no reference counterpart: bit 0 of force_small makes
- * mdlm_gemm_bf16 always use its 128x128 tile (default: 256x256 when
- * M % 256 == 0 and N >= 256) so that both configurations can be parity-tested
- * on any shape.  Bits 1 and 2 are timing ablations used by scratch/bench_gemm.py
- * only (2: skip the epilogue, 4: run the epilogue but drop its global stores);
- * outputs are then undefined. */
-int mdlm_gemm_set_tile(int force_small);
+                   const int32_t* out_row_map, int tile, void* stream);
 
 /* Weight gradient of an nn.Linear in the training step (autograd of
  * dit.py:220-232, 256, 277, 306/320 under diffusion.py:390-397): the
@@ -479,6 +474,30 @@ int mdlm_adamw_ema(float* p, const float* g, float* m, float* v, float* ema,
                    float eps, float weight_decay, int64_t step,
                    float ema_one_minus_decay, const float* sumsq, float max_norm,
                    float grad_scale, void* stream);
+
+/* ------------------------------------------------------- workspace sizes
+ * SURVEY 8(b) "Ownership": the caller allocates every buffer and sizes the
+ * workspaces with these queries (host arithmetic only; bytes, or -1 for a bad
+ * shape).  No reference counterpart: torch allocates inside its operators.
+ *   attn_bwd            : delta_ws
+ *   grad_sumsq          : partial_1024
+ *   gemm_bf16_splitk    : partials
+ *   gemm_tn_splitk      : partials (return value), bias_partials (*bias_partials_bytes)
+ *   embed_grad          : hot_partial
+ *   ln_modulate_bwd, dropout_gate_residual_bwd, colsum_bf16_partial : partial
+ *   transpose_bf16      : colsum_partial
+ *   masked_row_map      : gather and scatter, each (rows = B*L) */
+int64_t mdlm_attn_bwd_workspace_bytes(int n_seq, int H, int L);
+int64_t mdlm_grad_sumsq_workspace_bytes(void);
+int64_t mdlm_gemm_bf16_splitk_workspace_bytes(int64_t M, int N, int splits);
+int64_t mdlm_gemm_tn_splitk_workspace_bytes(int N, int K, int splits,
+                                            int64_t* bias_partials_bytes);
+int64_t mdlm_embed_grad_workspace_bytes(int64_t rows, int D);
+int64_t mdlm_ln_modulate_bwd_workspace_bytes(int64_t rows, int D);
+int64_t mdlm_dropout_gate_residual_bwd_workspace_bytes(int64_t rows, int D);
+int64_t mdlm_colsum_bf16_partial_workspace_bytes(int64_t rows, int N);
+int64_t mdlm_transpose_bf16_workspace_bytes(int R, int C);
+int64_t mdlm_masked_row_map_workspace_bytes(int64_t rows, int pad);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ kernels, flat AdamW/EMA buffers and the DDP gradient all-reduce on RCCL, on
 synthetic LM1B/OWT-shaped batches (the datasets need the network).
 """
 import json
+import os
 import sys
 import time
 
@@ -136,12 +137,21 @@ def _train(config, tokenizer):  # main.py:148-183 + diffusion.py:390-397, 254-25
   model.seed_rng(mdist.rank_seed(config.seed, rank))
   trainer = Trainer(model, max_norm=config.trainer.gradient_clip_val,
                     num_warmup_steps=config.lr_scheduler.num_warmup_steps)
+  # main.py:156-162: resume from checkpointing.resume_ckpt_path when it exists
+  ck = config.checkpointing
+  last = os.path.join(ck.save_dir, 'checkpoints', 'last.ckpt') if ck.save_dir else None
+  resume = ck.resume_ckpt_path or last
+  first_step = 0
+  if ck.resume_from_ckpt and resume and os.path.exists(resume):
+    first_step = int(trainer.load_checkpoint(resume))
+    if rank == 0:
+      print(json.dumps({'mode': 'train', 'resumed_from': resume, 'step': first_step}), flush=True)
   B, L = config.loader.batch_size, config.model.length
   accum = int(config.trainer.accumulate_grad_batches)
   g = torch.Generator(device='cuda').manual_seed(int(config.seed) + 1000 * rank)
   torch.manual_seed(int(config.seed) + rank)   # _sample_t draws from the default generator
   t0, tok = time.perf_counter(), 0
-  for step in range(int(config.trainer.max_steps)):
+  for step in range(first_step, int(config.trainer.max_steps)):
     for micro in range(accum):
       ids = torch.randint(0, tokenizer.vocab_size, (B, L), generator=g, device='cuda')
       ids[ids == model.mask_index] = 0
@@ -156,6 +166,10 @@ def _train(config, tokenizer):  # main.py:148-183 + diffusion.py:390-397, 254-25
       print(json.dumps({'mode': 'train', 'step': step + 1, 'trainer/loss': float(loss),
                         'lr': trainer.last_lr, 'tokens_per_sec': tok * world / dt,
                         'world_size': world}), flush=True)
+    if rank == 0 and last and (step + 1) % int(ck.every_n_train_steps) == 0:
+      trainer.save_checkpoint(last)
+  if rank == 0 and last:
+    trainer.save_checkpoint(last)
   return trainer
 
 

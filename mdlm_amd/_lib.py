@@ -48,9 +48,8 @@ SIGNATURES = {
   'mdlm_masked_row_map': [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
   'mdlm_gemm_bf16': [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32,
                      _i32, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp,
-                     _vp, _vp],
+                     _vp, _i32, _vp],
   'mdlm_attn_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
-  'mdlm_gemm_set_tile': [_i32],
   # training step
   'mdlm_attn_fwd_lse': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
   'mdlm_attn_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
@@ -73,6 +72,20 @@ SIGNATURES = {
   'mdlm_grad_sumsq_static': [_vp, _i64, _vp, _vp],
   'mdlm_adamw_ema': [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp, _f32, _f32, _vp],
   'mdlm_compact_active': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+}
+
+# workspace-size queries: host arithmetic, return int64 bytes (-1: bad shape)
+SIGNATURES_I64 = {
+  'mdlm_attn_bwd_workspace_bytes': [_i32, _i32, _i32],
+  'mdlm_grad_sumsq_workspace_bytes': [],
+  'mdlm_gemm_bf16_splitk_workspace_bytes': [_i64, _i32, _i32],
+  'mdlm_gemm_tn_splitk_workspace_bytes': [_i32, _i32, _i32, _vp],
+  'mdlm_embed_grad_workspace_bytes': [_i64, _i32],
+  'mdlm_ln_modulate_bwd_workspace_bytes': [_i64, _i32],
+  'mdlm_dropout_gate_residual_bwd_workspace_bytes': [_i64, _i32],
+  'mdlm_colsum_bf16_partial_workspace_bytes': [_i64, _i32],
+  'mdlm_transpose_bf16_workspace_bytes': [_i32, _i32],
+  'mdlm_masked_row_map_workspace_bytes': [_i64, _i32],
 }
 
 _lib = None
@@ -107,10 +120,23 @@ def _fn(lib, name):
 def check_symbols():
   """Every entry point declared in include/mdlm_hip.h must be exported."""
   lib = load()
-  missing = [n for n in SIGNATURES if not hasattr(lib, n)]
+  names = list(SIGNATURES) + list(SIGNATURES_I64)
+  missing = [n for n in names if not hasattr(lib, n)]
   if missing:
     raise RuntimeError(f'libmdlm_hip.so lacks symbols: {missing}')
-  return sorted(SIGNATURES) + ['mdlm_version', 'mdlm_last_error_string']
+  return sorted(names) + ['mdlm_version', 'mdlm_last_error_string']
+
+
+def call_i64(name, *args):
+  """A workspace-size query (no GPU involved): returns its int64 result."""
+  lib = load()
+  fn = getattr(lib, name)
+  if fn.argtypes is None:
+    fn.restype = C.c_int64
+    fn.argtypes = SIGNATURES_I64[name]
+  if name == 'mdlm_gemm_tn_splitk_workspace_bytes' and len(args) == 3:
+    args = args + (None,)
+  return int(fn(*args))
 
 
 def call(name, *args):

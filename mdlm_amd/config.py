@@ -85,6 +85,10 @@ DEFAULTS = dict(
                accumulate_grad_batches=None, gradient_clip_val=1.0, max_steps=1_000_000,
                log_every_n_steps=10),
   lr_scheduler=dict(name='constant_warmup', num_warmup_steps=2500),
+  # configs/config.yaml:96-101 + callbacks/checkpoint_every_n_steps.yaml
+  # (save_dir '' = no checkpoints; last.ckpt is rewritten every n steps and at the end)
+  checkpointing=dict(save_dir='', resume_from_ckpt=True, resume_ckpt_path=None,
+                     every_n_train_steps=500),
   noise=dict(type='loglinear', sigma_min=1e-4, sigma_max=20),
   data=dict(train='openwebtext', valid='openwebtext',
             tokenizer_name_or_path='gpt2', synthetic=True, vocab_size=50257),

@@ -126,6 +126,9 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_kernel(
 
   const int NT = L / KB;
   stage(0, 0);
+  // a wave's LDS-DMA must have landed before any wave reads the tile: explicit
+  // drain, not left to the compiler's waitcnt insertion
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int tt = 0; tt < NT; ++tt) {
     const int cur = tt & 1;
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_kernel(
         for (int t = 0; t < QT; ++t)
           oacc[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][c4], pf[t][c4], oacc[t][dt], 0, 0, 0);
       }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's LDS-DMA landed
     __syncthreads();
   }
 

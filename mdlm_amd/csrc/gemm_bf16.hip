@@ -56,8 +56,16 @@ struct GemmArgs {
   const int32_t* m_rows_dev;
   int tiles_m, tiles_n;
   int vec_ok;  // ldc / alignment allow 16-byte row stores
-  int dbg;     // timing experiments only (2: skip the epilogue, 4: drop the stores)
+  int dbg;     // MDLM_GEMM_ABLATION builds only (2: skip the epilogue, 4: drop the stores)
 };
+
+// Timing ablations exist only in builds with -DMDLM_GEMM_ABLATION (scratch/
+// experiments); the release library carries no such switch and no global state.
+#ifdef MDLM_GEMM_ABLATION
+#define GEMM_DBG(g) ((g).dbg)
+#else
+#define GEMM_DBG(g) 0
+#endif
 
 #define GLDS16(gptr, lptr) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
@@ -172,7 +180,7 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
       for (int it = 0; it < 8; ++it) {
         const int d = it * 8 + (lane >> 3), ch = lane & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(ep + d * 128 + ((ch ^ (d & 7)) * 16));
-        store16<true>(vb + (int64_t)d * L + ch * 8, v, g.dbg);
+        store16<true>(vb + (int64_t)d * L + ch * 8, v, GEMM_DBG(g));
       }
       return;
     }
@@ -218,7 +226,7 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + (lane >> 3), ch = lane & 7;
       const uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((ch ^ (row & 7)) * 16));
-      store16<true>(qb + row * 64 + ch * 8, v, g.dbg);
+      store16<true>(qb + row * 64 + ch * 8, v, GEMM_DBG(g));
     }
     return;
   } else {
@@ -278,7 +286,7 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
           for (int it = 0; it < MS * 2; ++it) {
             const int row = it * 8 + (lane >> 3), ch = lane & 7;
             const uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((ch ^ (row & 7)) * 16));
-            store16<true>(Ap0 + drs[it] * g.ldc + ch * 8, v, g.dbg);
+            store16<true>(Ap0 + drs[it] * g.ldc + ch * 8, v, GEMM_DBG(g));
           }
         }
         // pre-activation rows of the GELU-gradient epilogue, all loads in flight
@@ -322,7 +330,7 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
             v = make_uint4(o[0], o[1], o[2], o[3]);
           }
           const int64_t dr = drs[it];
-          if (dr >= 0) store16<true>(Cp0 + dr * g.ldc + ch * 8, v, g.dbg);
+          if (dr >= 0) store16<true>(Cp0 + dr * g.ldc + ch * 8, v, GEMM_DBG(g));
         }
       } else {
         // fp32 tile [MS*16][64], 16-B chunk index swizzled by (row & 15).
@@ -362,7 +370,7 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
             v.z = rs[it].z + gt.z * v.z; v.w = rs[it].w + gt.w * v.w;
           }
           const int64_t dr = dst_row(row);
-          if (dr >= 0) store16<false>(Cp0 + dr * g.ldc + ch * 4, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), g.dbg);
+          if (dr >= 0) store16<false>(Cp0 + dr * g.ldc + ch * 4, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), GEMM_DBG(g));
         }
       }
     } else {
@@ -505,7 +513,10 @@ void gemm_bf16_kernel(GemmArgs g) {
   set_src(tm, tn, sp);
   stage(0, 0);
   int buf = 0;          // stage holding the slab the next K step reads
-  __syncthreads();      // hipcc drains the LDS-DMA (vmcnt(0)) before the barrier
+  // the LDS-DMA of this wave must have landed before any wave reads the stage:
+  // explicit, not left to the compiler's waitcnt insertion
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   while (true) {
     int tm_next, tn_next, sp_next;
@@ -603,6 +614,7 @@ void gemm_bf16_kernel(GemmArgs g) {
           }
           __builtin_amdgcn_sched_group_barrier(0x008, 64 - 4 * (24 - R0), 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next slab's LDS-DMA landed
         __syncthreads();
         buf ^= 1;
       }
@@ -615,7 +627,7 @@ void gemm_bf16_kernel(GemmArgs g) {
 
     // ---- epilogue through this wave's 8 KiB of the stage read last ----------
     // (dbg bit 2, timing experiments only: skip it)
-    if (!(g.dbg & 2)) {
+    if (!(GEMM_DBG(g) & 2)) {
       // launder the lane id: the epilogue's per-lane addresses are then
       // recomputed per tile instead of being hoisted out of the tile loop and
       // spilled (their reloads would sit between the stores)
@@ -679,12 +691,10 @@ static int launch_cfg(GemmArgs g, hipStream_t s) {
   return 0;
 }
 
-static int g_force_small_tile = 0;  // test hook (mdlm_gemm_set_tile)
-static int g_dbg = 0;
-
+// tile: 0 = 256x256 when M % 256 == 0 and N >= 256, else 128x128; 1 = 128x128
 template <int EPI, typename TC>
-static int launch_gemm(const GemmArgs& g, hipStream_t s) {
-  if (g.M % 256 == 0 && g.N >= 256 && !g_force_small_tile)
+static int launch_gemm(const GemmArgs& g, hipStream_t s, int tile = 0) {
+  if (g.M % 256 == 0 && g.N >= 256 && tile != 1)
     return launch_cfg<EPI, TC, 2, 4, 8>(g, s);
   return launch_cfg<EPI, TC, 2, 2, 4>(g, s);
 }
@@ -692,12 +702,6 @@ static int launch_gemm(const GemmArgs& g, hipStream_t s) {
 }  // namespace mdlm
 
 using namespace mdlm;
-
-extern "C" int mdlm_gemm_set_tile(int force_small) {
-  g_force_small_tile = force_small & 1;
-  g_dbg = force_small & ~1;
-  return 0;
-}
 
 extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
                               const float* bias, void* C, int64_t ldc,
@@ -707,9 +711,10 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
                               const float* rot_cos, const float* rot_sin,
                               int n_heads, const int32_t* m_rows_dev,
                               const int32_t* out_sample_map,
-                              const int32_t* out_row_map, void* stream) {
+                              const int32_t* out_row_map, int tile, void* stream) {
   if (M == 0) return 0;
   MDLM_CHECK_ARG(A && W && C, "gemm_bf16: null pointer");
+  MDLM_CHECK_ARG((tile & ~7) == 0, "gemm_bf16: tile must be 0 (auto) or 1 (128x128)");
   MDLM_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_bf16: bad shape");
   MDLM_CHECK_ARG(M % 128 == 0, "gemm_bf16: M=%lld must be a multiple of 128", (long long)M);
   MDLM_CHECK_ARG(K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d", K, BK);
@@ -724,7 +729,8 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
   g.rows_per_mod = rows_per_mod > 0 ? rows_per_mod : 1; g.n_mod = n_mod > 0 ? n_mod : 1;
   g.mod_ld = mod_ld; g.out_sample_map = out_sample_map; g.out_row_map = out_row_map;
   g.rot_cos = rot_cos; g.rot_sin = rot_sin; g.n_heads = n_heads; g.m_rows_dev = m_rows_dev;
-  g.tiles_m = 0; g.tiles_n = 0; g.dbg = g_dbg;
+  g.tiles_m = 0; g.tiles_n = 0; g.dbg = tile & 6;   // ablation builds only
+  tile &= 1;
   g.ldw = K; g.splits = 1; g.c_split_stride = 0; g.aux = nullptr;
   hipStream_t s = (hipStream_t)stream;
   // 16-byte row stores: 8 bf16 or 4 fp32 per lane
@@ -736,25 +742,25 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
       MDLM_CHECK_ARG(dtype_c == MDLM_F32 || dtype_c == MDLM_BF16, "gemm_bf16: bad dtype_c");
       MDLM_CHECK_ARG(!out_sample_map || g.rows_per_mod % 64 == 0, "gemm_bf16: out_sample_map needs rows_per_mod %% 64 == 0");
       MDLM_CHECK_ARG(!(out_sample_map && out_row_map), "gemm_bf16: out_sample_map and out_row_map are exclusive");
-      if (dtype_c == MDLM_F32) return launch_gemm<MDLM_EPI_STORE, float>(g, s);
-      return launch_gemm<MDLM_EPI_STORE, bf16_t>(g, s);
+      if (dtype_c == MDLM_F32) return launch_gemm<MDLM_EPI_STORE, float>(g, s, tile);
+      return launch_gemm<MDLM_EPI_STORE, bf16_t>(g, s, tile);
     case MDLM_EPI_BIAS_GELU:
       MDLM_CHECK_ARG(ldc >= N && dtype_c == MDLM_BF16, "gemm_bf16: BIAS_GELU writes bf16 with ldc >= N");
-      return launch_gemm<MDLM_EPI_BIAS_GELU, bf16_t>(g, s);
+      return launch_gemm<MDLM_EPI_BIAS_GELU, bf16_t>(g, s, tile);
     case MDLM_EPI_GATE_RESIDUAL:
       MDLM_CHECK_ARG(gate && residual && dtype_c == MDLM_F32, "gemm_bf16: GATE_RESIDUAL needs gate, residual and fp32 C");
       MDLM_CHECK_ARG(ldc >= N && N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)residual & 15) == 0 && ((uintptr_t)gate & 15) == 0 && g.vec_ok,
                      "gemm_bf16: GATE_RESIDUAL needs N, ldc multiples of 4 and 16-byte aligned buffers");
       MDLM_CHECK_ARG(mod_ld % 4 == 0 && (g.n_mod == 1 || (mod_ld >= N && g.rows_per_mod % 64 == 0)),
                      "gemm_bf16: bad gate leading dimension / rows_per_mod %% 64 != 0");
-      return launch_gemm<MDLM_EPI_GATE_RESIDUAL, float>(g, s);
+      return launch_gemm<MDLM_EPI_GATE_RESIDUAL, float>(g, s, tile);
     case MDLM_EPI_QKV_ROTARY:
       MDLM_CHECK_ARG(rot_cos && rot_sin && n_heads > 0 && N == 3 * n_heads * 64,
                      "gemm_bf16: QKV_ROTARY needs head_dim 64 (N == 3*H*64) and rotary tables");
       MDLM_CHECK_ARG(rows_per_mod > 0 && rows_per_mod % 64 == 0 && M % rows_per_mod == 0,
                      "gemm_bf16: QKV_ROTARY needs M %% L == 0 and L %% 64 == 0");
       MDLM_CHECK_ARG(dtype_c == MDLM_BF16 && ((uintptr_t)C & 15) == 0, "gemm_bf16: QKV_ROTARY writes 16-byte aligned bf16");
-      return launch_gemm<MDLM_EPI_QKV_ROTARY, bf16_t>(g, s);
+      return launch_gemm<MDLM_EPI_QKV_ROTARY, bf16_t>(g, s, tile);
     default:
       MDLM_CHECK_ARG(false, "gemm_bf16: unknown epilogue %d", epilogue);
   }

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_splitk_kernel(TnArgs g) {
   set_src(tn, tk, sp);
   stage(0, 0);
   int buf = 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // explicit drain of the LDS-DMA
   __syncthreads();
 
   while (true) {
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_splitk_kernel(TnArgs g) {
         // this slab's MFMAs stay in front of the barrier (and of its vmcnt(0)): the
         // next slab's DMA then has the whole slab's compute to land
         __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next slab's LDS-DMA landed
         __syncthreads();
         buf ^= 1;
       }

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void qkv_grad_pack_kernel(
 constexpr int EG_ROWS = 128;
 __global__ __launch_bounds__(256) void embed_grad_kernel(const float* __restrict__ dx, const int64_t* __restrict__ idx,
                                                          float* __restrict__ dtable, int64_t rows, int D,
-                                                         int hot, float* __restrict__ hot_partial) {
+                                                         int vocab, int hot, float* __restrict__ hot_partial) {
   __shared__ int64_t sidx[EG_ROWS];
   const int nv = D / 4;
   const int64_t r0 = (int64_t)blockIdx.x * EG_ROWS;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void embed_grad_kernel(const float* __restrict
       const int64_t t = sidx[i];
       if (t == hot) {
         h.x += v.x; h.y += v.y; h.z += v.z; h.w += v.w;
-      } else {
+      } else if (t >= 0 && t < vocab) {   // never write outside the table (ids are validated on the host)
         float* d = dtable + t * D + c * 4;
         unsafeAtomicAdd(d + 0, v.x); unsafeAtomicAdd(d + 1, v.y);
         unsafeAtomicAdd(d + 2, v.z); unsafeAtomicAdd(d + 3, v.w);
@@ -753,7 +753,7 @@ extern "C" int mdlm_embed_grad(const float* dx, const int64_t* idx, float* dtabl
                  "embed_grad: hot_index needs a 16-byte aligned hot_partial workspace");
   const int64_t nb = (rows + EG_ROWS - 1) / EG_ROWS;
   MDLM_CHECK_ARG(nb < (1ll << 31), "embed_grad: too many rows");
-  embed_grad_kernel<<<(unsigned)nb, 256, 0, ST(stream)>>>(dx, idx, dtable, rows, D,
+  embed_grad_kernel<<<(unsigned)nb, 256, 0, ST(stream)>>>(dx, idx, dtable, rows, D, vocab,
                                                           hot_index >= 0 ? hot_index : -1,
                                                           hot_index >= 0 ? hot_partial : nullptr);
   MDLM_LAUNCH_CHECK();

@@ -125,6 +125,7 @@ class Diffusion(_Base):
     self._rng_offset = 0
     self._state = None
     self._eval_state = None
+    self._ema_restored = False
     self.last_nfe = None
     # bench.py's profiling pass (outside its timed region): dict(stride=k,
     # rows=[]) -> HIP events around every kernel of each k-th step, live row
@@ -159,9 +160,22 @@ class Diffusion(_Base):
     return self._rng_seed, off
 
   def on_load_checkpoint(self, checkpoint):  # diffusion.py:168-170
-    if self.ema and 'ema' in checkpoint:
+    if not self.ema:
+      return
+    if 'ema' in checkpoint:
       self.ema.load_state_dict(checkpoint['ema'])
       self.ema.move_shadow_params_to_device(self.device)
+      self._ema_restored = True
+    else:
+      # A file without an `ema` entry (plain state dict, .safetensors): the
+      # shadow would still hold the constructor-time (random-init) weights and
+      # restore_model_and_sample / validation would swap THOSE in over the
+      # loaded ones.  The loaded weights are the only ones there are: re-seed
+      # the shadow from them.
+      self.ema.shadow_params = [p.clone().detach() for p in self._params()
+                                if p.requires_grad]
+      self.ema.num_updates = 0
+      self._ema_restored = False
 
   def _params(self):
     return itertools.chain(self.backbone.parameters(), self.noise.parameters())
@@ -205,10 +219,11 @@ class Diffusion(_Base):
       es = self._eval_state
       if es is None or es['B'] != B or es['L'] != Lq or es['dev'] != x.device:
         i32 = dict(dtype=torch.int32, device=x.device)
+        n_map = ops.workspace_bytes('masked_row_map', B * Lq, 256) // 4
         es = dict(B=B, L=Lq, dev=x.device, ident=torch.arange(B, **i32),
                   n=torch.full((1,), B, **i32),
-                  gather=torch.zeros(B * Lq + 256, **i32),
-                  scatter=torch.zeros(B * Lq + 256, **i32),
+                  gather=torch.zeros(n_map, **i32),
+                  scatter=torch.zeros(n_map, **i32),
                   n_mrows=torch.zeros(1, **i32))
         self._eval_state = es
       ops.masked_row_map(x, es['ident'], es['n'], Lq, self.mask_index,
@@ -220,6 +235,7 @@ class Diffusion(_Base):
 
   def forward(self, x, sigma):
     """Returns log score (diffusion.py:312-327): SUBS log-probs (B, L, V)."""
+    ops.check_token_ids(x, self.vocab_size)
     logits = self._backbone_logits(x, sigma)
     return self._subs_parameterization(logits=logits, xt=x)
 
@@ -324,6 +340,7 @@ class Diffusion(_Base):
       return st
     dev = self.device
     i32 = dict(dtype=torch.int32, device=dev)
+    n_map = ops.workspace_bytes('masked_row_map', B * Lq, 256) // 4
     buf = torch.empty(B, Lq, ops.padded_vocab(self.vocab_size),
                       dtype=torch.bfloat16, device=dev)   # rows 16-byte aligned
     st = dict(
@@ -336,7 +353,7 @@ class Diffusion(_Base):
       changed=torch.ones(B, **i32), active=torch.zeros(B, **i32),
       n_active=torch.zeros(1, **i32), n_rows=torch.zeros(1, **i32),
       nfe=torch.zeros(1, dtype=torch.int64, device=dev),
-      gather=torch.zeros(B * Lq + 256, **i32), scatter=torch.zeros(B * Lq + 256, **i32),
+      gather=torch.zeros(n_map, **i32), scatter=torch.zeros(n_map, **i32),
       n_mrows=torch.zeros(1, **i32), fresh=torch.ones(B, **i32),
       zeros=torch.zeros(B, dtype=torch.float32, device=dev),
       # rows the fast race re-evaluated in the defining arithmetic (diagnostic)
@@ -650,6 +667,7 @@ class Diffusion(_Base):
                                 '(text8-crop) is out of scope')
     if attention_mask is None:
       attention_mask = torch.ones_like(x0, dtype=torch.float32)
+    ops.check_token_ids(x0, self.vocab_size)
     nlls = self._forward_pass_diffusion(x0, t=t, u=u,
                                         attention_mask=attention_mask)
     sums = ops.nll_sums(nlls, attention_mask)

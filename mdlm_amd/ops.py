@@ -346,8 +346,11 @@ def ln_modulate(x, ln_w, shift, scale, out, rows_per_mod, n_mod=1, mod_ld=0,
 def gemm_bf16(A, W, C, epilogue=_lib.EPI_STORE, bias=None, gate=None,
               residual=None, rows_per_mod=1, n_mod=1, mod_ld=0, rot_cos=None,
               rot_sin=None, n_heads=0, m_rows_dev=None, out_sample_map=None,
-              out_row_map=None, ldc=None, M=None):
-  """C = epilogue(A @ W^T); see include/mdlm_hip.h (mdlm_gemm_bf16)."""
+              out_row_map=None, ldc=None, M=None, tile=None):
+  """C = epilogue(A @ W^T); see include/mdlm_hip.h (mdlm_gemm_bf16).  tile: 0 =
+  the library chooses, 1 = 128x128 (None: DEFAULT_GEMM_TILE)."""
+  if tile is None:
+    tile = DEFAULT_GEMM_TILE
   if M is None:
     M = A.shape[0]
   K = A.shape[1]
@@ -360,7 +363,7 @@ def gemm_bf16(A, W, C, epilogue=_lib.EPI_STORE, bias=None, gate=None,
        C.data_ptr(), int(ldc), _DT[C.dtype], int(M), N, K, int(epilogue),
        _p(gate), _p(residual), int(rows_per_mod), int(n_mod), int(mod_ld),
        _p(rot_cos), _p(rot_sin), int(n_heads), _p(m_rows_dev),
-       _p(out_sample_map), _p(out_row_map), _stream())
+       _p(out_sample_map), _p(out_row_map), int(tile), _stream())
   return C
 
 
@@ -466,9 +469,44 @@ def masked_row_map(x, active, n_active, L, mask_index, gather, scatter, n_out,
        gather.data_ptr(), scatter.data_ptr(), n_out.data_ptr(), _stream())
 
 
+def check_token_ids(ids, vocab):
+  """Raise on ids outside [0, vocab): the reference's embedding lookup raises /
+  device-asserts on them (dit.py:298-299), while the kernels clamp (forward) as
+  a memory-safety net only.  One host read of a 2-element tensor: call it at
+  API boundaries, not inside the sampling loop."""
+  lo, hi = torch.aminmax(ids)
+  lo, hi = int(lo), int(hi)
+  if lo < 0 or hi >= vocab:
+    raise IndexError(f'token id out of range: min {lo}, max {hi}, vocabulary size {vocab} '
+                     '(tokenizer / checkpoint mismatch?)')
+
+
+# tile argument of gemm_bf16 calls that do not pass one.  Host-side (Python)
+# only: the tests flip it to run every GEMM of the backbone on the 128x128
+# configuration; the library itself holds no tuning state.
+DEFAULT_GEMM_TILE = 0
+
+
 def gemm_set_tile(force_small):
-  """Test hook: force the 128x128 GEMM tile (see mdlm_gemm_set_tile)."""
-  call('mdlm_gemm_set_tile', int(force_small))
+  """Tests / scratch benches: default `tile` of later gemm_bf16 calls (bit 0:
+  128x128; bits 1-2 only act in -DMDLM_GEMM_ABLATION builds)."""
+  global DEFAULT_GEMM_TILE
+  DEFAULT_GEMM_TILE = int(force_small)
+
+
+def workspace_bytes(op, *args):
+  """`mdlm_<op>_workspace_bytes(...)` of include/mdlm_hip.h (host arithmetic)."""
+  n = _lib.call_i64(f'mdlm_{op}_workspace_bytes', *[int(a) for a in args])
+  if n < 0:
+    raise RuntimeError(f'mdlm_{op}_workspace_bytes{args}: bad shape')
+  return n
+
+
+def workspace(op, *args, device=None, dtype=torch.float32):
+  """Workspace tensor sized by the library's query."""
+  nbytes = workspace_bytes(op, *args)
+  return torch.empty(nbytes // torch.empty((), dtype=dtype).element_size(),
+                     dtype=dtype, device=device)
 
 
 # ------------------------------------------------------- training step (f-3)

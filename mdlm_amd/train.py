@@ -97,6 +97,12 @@ class Trainer:
     if dev.type != 'cuda':
       raise RuntimeError('mdlm_amd.Trainer needs the model on a ROCm device; '
                          'there is no CPU fallback')
+    if model.T > 0:
+      # forward_backward uses the continuous-time weight dsigma / expm1(sigma)
+      # (diffusion.py:893-894); the discrete-time branch (849-853, 329-358) is
+      # evaluated by Diffusion._loss only
+      raise NotImplementedError('Trainer: T > 0 (discrete-time loss) is not implemented; '
+                                'training would optimise a different loss from validation')
     self.model, self.bb, self.dev = model, bb, dev
     self.lr = cfg.optim.lr if lr is None else lr
     self.betas = (cfg.optim.beta1, cfg.optim.beta2) if betas is None else betas
@@ -130,8 +136,15 @@ class Trainer:
     self.E = None
     if self.ema_decay > 0:
       self.E = self.P.clone()
-      if getattr(model, 'ema', None):
-        model.ema.shadow_params = [self._view(self.E, n) for n in self.names]
+      ema = getattr(model, 'ema', None)
+      if ema:
+        # an EMA restored by on_load_checkpoint (diffusion.py:168-170) is kept:
+        # its shadow parameters move into the flat buffer, its update count
+        # continues the decay warm-up of models/ema.py:44-46
+        if getattr(model, '_ema_restored', False):
+          for n, sp in zip(self.names, ema.shadow_params):
+            self._view(self.E, n).copy_(sp.to(dev))
+        ema.shadow_params = [self._view(self.E, n) for n in self.names]
     bb.refresh()
     # DDP buckets in the order the backward completes them: output layer,
     # blocks L-1..0, then everything before block 0 (embedding, sigma_map)
@@ -151,7 +164,7 @@ class Trainer:
     self.A, self.micro = None, 0   # accumulation carry (allocated on first use)
     self.last_lr = None
     self._sumsq = torch.zeros(1, device=dev)
-    self._sumsq_part = torch.empty(1024, device=dev)
+    self._sumsq_part = ops.workspace('grad_sumsq', device=dev)
     self.last_grad_norm = None
 
   # ---------------------------------------------------------------- helpers
@@ -166,6 +179,67 @@ class Trainer:
     """models/ema.py:89-92 layout."""
     return dict(decay=self.ema_decay, num_updates=self.step_count,
                 shadow_params=[self._view(self.E, n) for n in self.names])
+
+  # -------------------------------------------------------------- checkpoints
+  def state_dict(self):
+    """Everything a resumed run needs beyond the weights: Adam moments, EMA
+    shadow, optimizer-step count and the Philox stream position (the reference
+    gets these from Lightning's checkpoint: optimizer_states, loops, and the
+    `ema` entry written by on_save_checkpoint, diffusion.py:172-181)."""
+    return dict(P=self.P, M1=self.M1, M2=self.M2, E=self.E, step_count=self.step_count,
+                rng_seed=self.model._rng_seed, rng_offset=self.model._rng_offset,
+                n_flat=self.n_flat)
+
+  def load_state_dict(self, sd):
+    if int(sd['n_flat']) != self.n_flat:
+      raise ValueError(f"trainer state holds {sd['n_flat']} flat elements, model has {self.n_flat}")
+    self.P.copy_(sd['P']); self.M1.copy_(sd['M1']); self.M2.copy_(sd['M2'])
+    if self.E is not None and sd.get('E') is not None:
+      self.E.copy_(sd['E'])
+    self.W16.copy_(self.P)
+    self.step_count = int(sd['step_count'])
+    self.model.seed_rng(int(sd['rng_seed']), int(sd['rng_offset']))
+    if getattr(self.model, 'ema', None):
+      self.model.ema.num_updates = self.step_count
+    self.bb.refresh()
+
+  def save_checkpoint(self, path):
+    """Reference (Lightning) layout: `state_dict` with `backbone.*` keys, `ema`
+    as models/ema.py:89-92, `global_step`; plus `trainer_state` (this build's
+    flat optimizer state).  Tensors and plain containers only, so the file
+    loads with torch.load(weights_only=True)."""
+    import os
+    sd = {'backbone.' + k: v.detach().clone() for k, v in self.bb.state_dict().items()}
+    ckpt = {'state_dict': sd, 'global_step': self.step_count,
+            'trainer_state': {k: (v.detach().clone() if torch.is_tensor(v) else v)
+                              for k, v in self.state_dict().items()}}
+    if self.E is not None:
+      ckpt['ema'] = dict(decay=self.ema_decay, num_updates=self.step_count,
+                         shadow_params=[self._view(self.E, n).detach().clone() for n in self.names])
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    tmp = path + '.tmp'
+    torch.save(ckpt, tmp)
+    os.replace(tmp, path)
+
+  def load_checkpoint(self, path):
+    ckpt = torch.load(path, map_location=self.dev, weights_only=True)
+    if 'trainer_state' in ckpt:
+      self.load_state_dict(ckpt['trainer_state'])
+    else:  # a reference checkpoint: weights (+ EMA) only, optimizer state starts fresh
+      bbsd = {k[len('backbone.'):]: v for k, v in ckpt['state_dict'].items()
+              if k.startswith('backbone.')}
+      for n in self.names:
+        self._view(self.P, n).copy_(bbsd[n])
+      self.W16.copy_(self.P)
+      if self.E is not None:
+        if 'ema' in ckpt:
+          for n, sp in zip(self.names, ckpt['ema']['shadow_params']):
+            self._view(self.E, n).copy_(sp)
+          self.step_count = int(ckpt['ema'].get('num_updates', 0))
+        else:
+          self.E.copy_(self.P)
+      self.bb.refresh()
+    return ckpt.get('global_step', self.step_count)
 
   def _workspace(self, B, L):
     key = (B, L)
@@ -197,17 +271,20 @@ class Trainer:
       logits=torch.zeros(Mp, Vp, dtype=bf, device=dev), dlogits=e(Mp, Vp),
       samples=torch.arange(B, dtype=torch.int32, device=dev),
       n_samples=torch.tensor([B], dtype=torch.int32, device=dev),
-      gather=torch.zeros(Mp + 256, dtype=torch.int32, device=dev),
-      scatter=torch.zeros(Mp + 256, dtype=torch.int32, device=dev),
+      gather=torch.zeros(ops.workspace_bytes('masked_row_map', Mp, 256) // 4,
+                         dtype=torch.int32, device=dev),
+      scatter=torch.zeros(ops.workspace_bytes('masked_row_map', Mp, 256) // 4,
+                          dtype=torch.int32, device=dev),
       n_out=torch.zeros(1, dtype=torch.int32, device=dev),
-      hot=e((M + 127) // 128, D, dt=torch.float32),
+      hot=ops.workspace('embed_grad', M, D, device=dev).view(-1, D),
       cos=fr.cos().to(bf).float().contiguous(), sin=fr.sin().to(bf).float().contiguous(),
       dx=e(M, D, dt=torch.float32), d_md=e(M, D), d_m4=e(M, 4 * D), d_m4b=e(M, 4 * D),
       d_qkv=e(M, 3 * D), dq=e(M * D), dk=e(M * D), dv=e(M * D),
-      delta=e(B * H * L, dt=torch.float32),
+      delta=ops.workspace('attn_bwd', B, H, L, device=dev),
       tA=e(max(Vp, 4 * D) * Mp), tB=e(4 * D * Mp), wT=e(max(Vp * D, 4 * D * D)),
       wvT=torch.zeros(D, Vp, dtype=bf, device=dev),
-      part3=e(nblk, 3, D, dt=torch.float32), part1=e(nblk, D, dt=torch.float32),
+      part3=ops.workspace('ln_modulate_bwd', M, D, device=dev).view(nblk, 3, D),
+      part1=ops.workspace('dropout_gate_residual_bwd', M, D, device=dev).view(nblk, D),
       bias_v=e(Vp, dt=torch.float32),
       partc=e((Mp + 63) // 64, max(Vp, 4 * D), dt=torch.float32))
     return self._ws
@@ -296,6 +373,7 @@ class Trainer:
     if M % 128 or L % 64 or D % 128:
       raise ValueError('Trainer: B*L must be a multiple of 128, L of 64, hidden of 128')
     ws = self._workspace(B, L)
+    ops.check_token_ids(x0, V)
     if attention_mask is None:
       attention_mask = torch.ones(B, L, dtype=torch.float32, device=self.dev)
     attention_mask = attention_mask.float()

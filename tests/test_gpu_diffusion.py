@@ -512,6 +512,14 @@ def test_checkpoint_ingestion(ops, tmp_path):
                  SyntheticTokenizer(vocab_size=V - 1, eos_token_id=7)).cuda()
   cli._load_backbone_weights(m3, st_path)
   assert torch.equal(m3.backbone(x, torch.zeros(4).cuda()), before)
+  # no `ema` entry in the file: sampling must run on the LOADED weights, not on
+  # the constructor-time shadow (random init with a zero output layer)
+  assert m3.ema is not None and not m3._ema_restored
+  m3.seed_rng(123)
+  with_ema = m3.restore_model_and_sample(num_steps=8)
+  m3.ema = None
+  m3.seed_rng(123)
+  assert torch.equal(with_ema, m3.restore_model_and_sample(num_steps=8))
 
 
 def test_full_size_configs1_backbone_and_fused_step(ops):

@@ -565,3 +565,70 @@ def test_training_step_without_masked_tokens(ops):
   tr.step_count = 5                          # past the warm-up: lr > 0
   tr.optimizer_step()
   assert torch.equal(tr.P, before)
+
+
+def test_trainer_checkpoint_roundtrip_and_resume(ops, tmp_path):
+  """save -> load into a fresh Trainer -> one more step == the uninterrupted
+  run, bit for bit (weights, Adam moments, EMA shadow, step count, Philox
+  offset; the reference gets this from Lightning checkpoints + the `ema` entry of
+  on_save_checkpoint / on_load_checkpoint, diffusion.py:168-181).  The file has
+  the reference layout (`state_dict` with backbone.* keys + `ema`) and loads with
+  weights_only=True."""
+  B = 4
+  model, cfg, p, tr = _make_trainer(0.1, extra=['training.ema=0.999'])
+  L = cfg.model.length
+  batches = [_batch(B, L, seed=s) for s in range(4)]
+
+  def step(tr_, b):
+    x0, attn, t, u = b
+    tr_.forward_backward(x0.cuda(), attn.cuda(), t=t.cuda(), u_xt=u.cuda())
+    tr_.optimizer_step()
+  for b in batches[:3]:
+    step(tr, b)
+  path = str(tmp_path / 'checkpoints' / 'last.ckpt')
+  tr.save_checkpoint(path)
+  ckpt = torch.load(path, map_location='cpu', weights_only=True)
+  assert set(ckpt) >= {'state_dict', 'ema', 'global_step', 'trainer_state'}
+  assert all(k.startswith('backbone.') for k in ckpt['state_dict'])
+  assert ckpt['global_step'] == 3 and ckpt['ema']['num_updates'] == 3
+  assert len(ckpt['ema']['shadow_params']) == len(list(model.backbone.parameters()))
+  step(tr, batches[3])   # the uninterrupted run
+
+  model2, _, _, tr2 = _make_trainer(0.1, seed=11, extra=['training.ema=0.999'])
+  assert tr2.load_checkpoint(path) == 3
+  assert tr2.step_count == 3 and model2._rng_offset == ckpt['trainer_state']['rng_offset']
+  step(tr2, batches[3])
+  for name in ('P', 'M1', 'M2', 'E', 'W16'):
+    assert torch.equal(getattr(tr, name), getattr(tr2, name)), name
+  assert tr2.step_count == tr.step_count == 4 and tr2.last_lr == tr.last_lr
+
+  # the same file through the inference loader (main.py): weights + restored EMA,
+  # and a Trainer built on that model keeps the restored EMA instead of resetting it
+  import main as cli
+  model3, _, _, _ = _make_trainer(0.1, seed=12, extra=['training.ema=0.999'])
+  from mdlm_amd.config import load_config
+  from mdlm_amd.diffusion import Diffusion
+  from mdlm_amd.tokenizer import SyntheticTokenizer
+  from mdlm_amd.train import Trainer
+  m4 = Diffusion(load_config(['model=tiny', 'loader.eval_batch_size=4', 'training.ema=0.999']),
+                 SyntheticTokenizer(vocab_size=V_T, eos_token_id=7, mask_token_id=MASK_T)).cuda()
+  cli._load_backbone_weights(m4, path)
+  assert m4._ema_restored and m4.ema.num_updates == 3
+  tr4 = Trainer(m4, lr=3e-3, num_warmup_steps=2, dropout=0.1)
+  for n, sp in zip(tr4.names, ckpt['ema']['shadow_params']):
+    assert torch.equal(tr4._view(tr4.E, n).cpu(), sp), n
+
+
+def test_trainer_rejects_discrete_time_and_bad_ids(ops):
+  """T > 0 would train on a different loss from validation (diffusion.py:849-853,
+  329-358): refused.  Token ids outside the vocabulary raise (the reference's
+  embedding lookup asserts) instead of being clamped silently."""
+  with pytest.raises(NotImplementedError, match='T > 0'):
+    _make_trainer(0.0, extra=['T=8'])
+  model, cfg, p, tr = _make_trainer(0.0)
+  x0, attn, t, u = _batch(4, cfg.model.length)
+  x0[0, 3] = V_T + 5
+  with pytest.raises(IndexError, match='token id out of range'):
+    tr.forward_backward(x0.cuda(), attn.cuda(), t=t.cuda(), u_xt=u.cuda())
+  with pytest.raises(IndexError, match='token id out of range'):
+    model._loss(x0.cuda(), attn.cuda())

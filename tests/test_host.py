@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
   lib = _lib.load()
   for name in declared:
     assert hasattr(lib, name), f'{name} declared in include/mdlm_hip.h but not exported'
-  bound = set(_lib.SIGNATURES) | {'mdlm_version', 'mdlm_last_error_string'}
+  bound = (set(_lib.SIGNATURES) | set(_lib.SIGNATURES_I64)
+           | {'mdlm_version', 'mdlm_last_error_string'})
   assert set(declared) == bound, set(declared) ^ bound
   assert _lib.check_symbols()
   assert lib.mdlm_version() >= 100
@@ -53,9 +54,36 @@ def test_argument_errors_do_not_need_a_gpu():
     _lib.call('mdlm_subs_logprobs', 0, 8, 0, 0, 0, 8, 0, 1, 8, 7, 0, 0)
   with pytest.raises(RuntimeError, match='multiple of 128'):
     _lib.call('mdlm_gemm_bf16', 16, 64, 16, 0, 16, 64, 1, 100, 64, 64, 0, 0, 0, 1, 1, 0,
-              0, 0, 0, 0, 0, 0, 0)
+              0, 0, 0, 0, 0, 0, 0, 0)
   with pytest.raises(RuntimeError, match='multiple of'):
     _lib.call('mdlm_attn_fwd', 16, 16, 16, 16, 1, 1, 100, 0, 0)
+
+
+def test_workspace_queries_match_what_the_host_side_allocates():
+  """SURVEY 8(b) "Ownership": workspaces are sized by `*_workspace_bytes`
+  (host arithmetic: runs without a GPU).  The sizes must be the ones the kernels
+  index (header prose) and the ones mdlm_amd allocates."""
+  from mdlm_amd import ops
+  B, H, L, D, M = 4, 12, 128, 768, 512
+  assert ops.workspace_bytes('attn_bwd', B, H, L) == B * H * L * 4
+  assert ops.workspace_bytes('grad_sumsq') == 4096
+  assert ops.workspace_bytes('gemm_bf16_splitk', 768, 768, 8) == 8 * 768 * 768 * 4
+  assert ops.workspace_bytes('gemm_tn_splitk', 768, 3072, 28) == 28 * 768 * 3072 * 4
+  assert ops.workspace_bytes('embed_grad', M + 1, D) == (M // 128 + 1) * D * 4
+  assert ops.workspace_bytes('ln_modulate_bwd', M, D) == (M // 32) * 3 * D * 4
+  assert ops.workspace_bytes('dropout_gate_residual_bwd', M, D) == (M // 32) * D * 4
+  assert ops.workspace_bytes('colsum_bf16_partial', M, 3072) == (M // 128) * 3072 * 4
+  assert ops.workspace_bytes('transpose_bf16', 100, 64) == 2 * 64 * 4
+  assert ops.workspace_bytes('masked_row_map', M, 256) == (M + 256) * 4
+  with pytest.raises(RuntimeError, match='bad shape'):
+    ops.workspace_bytes('attn_bwd', 1, 0, 128)
+  w = ops.workspace('ln_modulate_bwd', M, D, device='cpu')
+  assert w.dtype == torch.float32 and w.numel() == (M // 32) * 3 * D
+  # the trainer and the sampler size their workspaces with the queries
+  src = open(os.path.join(ROOT, 'mdlm_amd', 'train.py')).read()
+  for op in ('attn_bwd', 'grad_sumsq', 'embed_grad', 'ln_modulate_bwd',
+             'dropout_gate_residual_bwd'):
+    assert f"workspace('{op}'" in src, op
 
 
 def test_no_cpu_fallback():
