@@ -389,6 +389,8 @@ def main():
   ap.add_argument('--profile-stride', type=int, default=8,
                   help='profiling batch (after the timed region): HIP events around '
                        'every kernel of each k-th denoising step; 0 = skip')
+  ap.add_argument('--set', action='append', default=[], metavar='KEY=VALUE',
+                  help='extra config override (same-box ablations), e.g. sampling.lse_from_gemm=false')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-policy-compare', action='store_true')
   ap.add_argument('--no-eval', action='store_true')
@@ -417,7 +419,8 @@ def main():
   fast = args.race == 'fast'
   cfg = load_config([f'model={args.model}', f'loader.eval_batch_size={args.batch}',
                      f'sampling.steps={args.T}', f'sampling.cache_policy={args.cache_policy}',
-                     f'sampling.fast_math={str(fast).lower()}', f'trainer.devices={world}'])
+                     f'sampling.fast_math={str(fast).lower()}', f'trainer.devices={world}',
+                     *args.set])
   model = build_model(cfg, seed=1)
   model.seed_rng(mdist.rank_seed(cfg.seed, rank))
   B, L, V = args.batch, cfg.model.length, model.vocab_size
@@ -485,7 +488,8 @@ def main():
                         'bit-exact; every element in the defining arithmetic '
                         '(sampling.fast_math=false)'),
                'rng': 'in-kernel Philox4x32-7',
-               'parallelism': f'replicas x{world}'},
+               'parallelism': f'replicas x{world}',
+               **({'overrides': args.set} if args.set else {})},
     'dist': dist_info,
     'nfe_per_sample': round(nfe_last / B, 1),
     'race_rows_re_evaluated_exactly': n_exact,

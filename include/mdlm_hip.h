@@ -271,6 +271,14 @@ int mdlm_ln_modulate(const float* x, const float* ln_w, const float* shift,
  *                    (q | k | vt).  rows_per_mod = L.
  * m_rows_dev: optional device int32 with the number of live rows (tiles
  * beyond it exit), so a fixed launch can serve a device-side active count.
+ * lse_partials_out (optional; bf16 STORE with M % 256 == 0 only): SUBS row
+ * statistics out of the epilogue (diffusion.py:263-268 fused
+ * behind dit.py:317-321).  For every output row and every group of 64 columns
+ * the pair (max, sum exp(y - max)) over the bf16-rounded outputs y, column
+ * lse_skip_col (the mask token: its SUBS logit is shifted by -1e6, so it adds
+ * exp(.) = 0; -1 = none) excluded; layout [row / 256][ceil(N/64)][row % 256]
+ * float2, mdlm_gemm_lse_partials_workspace_bytes(M, N) bytes, indexed by the
+ * GEMM's own (compact) row.  mdlm_lse_combine turns them into the row lse.
  * tile: 0 = choose (256x256 when M % 256 == 0 and N >= 256, else 128x128),
  * 1 = 128x128 always -- per call, so both configurations can be parity-tested on
  * any shape; the library holds no tuning state. */
@@ -280,7 +288,16 @@ int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
                    int64_t rows_per_mod, int n_mod, int64_t mod_ld,
                    const float* rot_cos, const float* rot_sin, int n_heads,
                    const int32_t* m_rows_dev, const int32_t* out_sample_map,
-                   const int32_t* out_row_map, int tile, void* stream);
+                   const int32_t* out_row_map, float* lse_partials_out,
+                   int lse_skip_col, int tile, void* stream);
+
+/* lse[out_row_map[r]] (or lse[r] when the map is NULL; entries < 0 skipped) =
+ * log-sum-exp of row r from the partials mdlm_gemm_bf16 wrote, for r <
+ * *n_rows_dev (NULL: r < M): the SUBS normaliser of diffusion.py:265-268
+ * without a pass over the (rows, V) logits. */
+int mdlm_lse_combine(const float* partials, int64_t M, int N,
+                     const int32_t* out_row_map, const int32_t* n_rows_dev,
+                     float* lse, void* stream);
 
 /* Weight gradient of an nn.Linear in the training step (autograd of
  * dit.py:220-232, 256, 277, 306/320 under diffusion.py:390-397): the
@@ -498,6 +515,7 @@ int64_t mdlm_dropout_gate_residual_bwd_workspace_bytes(int64_t rows, int D);
 int64_t mdlm_colsum_bf16_partial_workspace_bytes(int64_t rows, int N);
 int64_t mdlm_transpose_bf16_workspace_bytes(int R, int C);
 int64_t mdlm_masked_row_map_workspace_bytes(int64_t rows, int pad);
+int64_t mdlm_gemm_lse_partials_workspace_bytes(int64_t M, int N);   /* lse_partials_out */
 
 #ifdef __cplusplus
 }

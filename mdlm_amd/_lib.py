@@ -48,7 +48,8 @@ SIGNATURES = {
   'mdlm_masked_row_map': [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
   'mdlm_gemm_bf16': [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32,
                      _i32, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp,
-                     _vp, _i32, _vp],
+                     _vp, _vp, _i32, _i32, _vp],
+  'mdlm_lse_combine': [_vp, _i64, _i32, _vp, _vp, _vp, _vp],
   'mdlm_attn_fwd': [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
   # training step
   'mdlm_attn_fwd_lse': [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
@@ -86,6 +87,7 @@ SIGNATURES_I64 = {
   'mdlm_colsum_bf16_partial_workspace_bytes': [_i64, _i32],
   'mdlm_transpose_bf16_workspace_bytes': [_i32, _i32],
   'mdlm_masked_row_map_workspace_bytes': [_i64, _i32],
+  'mdlm_gemm_lse_partials_workspace_bytes': [_i64, _i32],
 }
 
 _lib = None

@@ -64,13 +64,15 @@ DEFAULTS = dict(
                 stride_length=1, num_strides=1,
                 # mdlm_amd extensions.  Result-identical knobs (same token ids on
                 # the same random stream, checked bit for bit by the GPU tests):
-                # fused, cache_policy, masked_rows_only, and fast_math -- true
+                # fused, cache_policy, masked_rows_only, lse_from_gemm (row lse out of
+                # the vocabulary GEMM's epilogue: same value to ~1e-6, same tokens up
+                # to exact mask-key ties), and fast_math -- true
                 # ranks the race by approximate keys and re-evaluates near-ties
                 # in the defining arithmetic, false evaluates every element in it
                 # (include/mdlm_hip.h).  lazy_unmask is NOT result-identical
                 # (same law, different map from random numbers): opt-in.
                 fused=True, cache_policy='sample', fast_math=True,
-                masked_rows_only=True, lazy_unmask=False,
+                masked_rows_only=True, lse_from_gemm=True, lazy_unmask=False,
                 p_x0_dtype='bf16'),
   training=dict(ema=0.9999, antithetic_sampling=True,
                 importance_sampling=False, sampling_eps=1e-3,

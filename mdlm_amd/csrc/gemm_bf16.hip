@@ -54,6 +54,9 @@ struct GemmArgs {
   const int32_t* out_row_map;
   const float* rot_cos; const float* rot_sin; int n_heads;
   const int32_t* m_rows_dev;
+  // EPI_STORE bf16 only: per (row, 64-column group) softmax partials (max, sum of
+  // exp(x - max)) of the bf16-rounded outputs, column lse_skip excluded
+  float2* lse_part; int lse_skip; int lse_ng;
   int tiles_m, tiles_n;
   int vec_ok;  // ldc / alignment allow 16-byte row stores
   int dbg;     // MDLM_GEMM_ABLATION builds only (2: skip the epilogue, 4: drop the stores)
@@ -133,6 +136,76 @@ struct EpiConsts {
   bool ok;       // interior wave tile with 16-byte row stores: vector path
   bool gt_tile;  // gt holds the gate row of the whole wave tile (one sample)
 };
+
+// Row statistics of the vocabulary projection, taken from the accumulators while
+// they are still in registers (SUBS max / sum out of the vocab-GEMM
+// epilogue; reference diffusion.py:263-268 after models/dit.py:317-321).  For every
+// row of the MS*16-row sub-tile and this wave's 64 columns:
+//   m = max_v y_v,  s = sum_v exp(y_v - m),   y = bf16(acc + bias), exactly the
+// values the epilogue stores; column lse_skip (the mask token, whose SUBS logit is
+// shifted by -1e6, i.e. contributes exp(.) = 0) and columns >= N excluded.
+// A lane holds 16 of a row's 64 values (4 per n); lanes fr, fr+16, fr+32, fr+48
+// share the row: in-lane reduction, then two cross-lane steps.  Layout of the
+// partials: [row / 256][group = column / 64][row % 256] float2 -- 16 consecutive
+// rows per store instruction are contiguous (128 bytes); mdlm_lse_combine reduces
+// the groups of a row.
+template <int MT, int M0, int MS>
+__device__ __forceinline__ void lse_partials(const f32x4 (&accf)[MT][4], int64_t grow0, int gcol0,
+                                             const EpiConsts& ec, const GemmArgs& g, int lane) {
+  const int fq = lane >> 4, fr = lane & 15;
+  constexpr float L2E = 1.4426950408889634f;
+  const bool plain = ec.ok && !(g.lse_skip >= gcol0 && g.lse_skip < gcol0 + 64);   // wave-uniform
+  float bias_e[4][4];
+  if (!plain) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = gcol0 + n * 16 + fq * 4 + j;
+        bias_e[n][j] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < MS; ++m) {
+    float y[16];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const f32x4 a = accf[M0 + m][n];
+      if (plain) {
+        const f32x2 lo = bf16_round2(a[0] + ec.bias4[n].x, a[1] + ec.bias4[n].y);
+        const f32x2 hi = bf16_round2(a[2] + ec.bias4[n].z, a[3] + ec.bias4[n].w);
+        y[n * 4 + 0] = lo.x; y[n * 4 + 1] = lo.y; y[n * 4 + 2] = hi.x; y[n * 4 + 3] = hi.y;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = gcol0 + n * 16 + fq * 4 + j;
+          y[n * 4 + j] = (col < g.N && col != g.lse_skip) ? bf16_round(a[j] + bias_e[n][j]) : -INFINITY;
+        }
+      }
+    }
+    float mx = fmaxf(fmaxf(y[0], y[1]), y[2]);
+#pragma unroll
+    for (int k = 3; k < 15; k += 2) mx = fmaxf(fmaxf(mx, y[k]), y[k + 1]);
+    mx = fmaxf(mx, y[15]);
+    const float nm = (mx == -INFINITY) ? 0.f : -mx * L2E;   // all 16 excluded: s = 0
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sm += __builtin_amdgcn_exp2f(__builtin_fmaf(y[k], L2E, nm));
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const float mo = __shfl_xor(mx, o), so = __shfl_xor(sm, o);
+      const float M = fmaxf(mx, mo);
+      const float ea = (mx == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mx - M) * L2E);
+      const float eb = (mo == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mo - M) * L2E);
+      sm = sm * ea + so * eb;
+      mx = M;
+    }
+    if (fq == 0) {
+      const int64_t R = grow0 + m * 16 + fr;
+      g.lse_part[((R >> 8) * g.lse_ng + (gcol0 >> 6)) * 256 + (R & 255)] = make_float2(mx, sm);
+    }
+  }
+}
 
 // Epilogue of MS*16 rows x 64 columns of a wave tile (m sub-tiles M0..M0+MS-1).
 // SWAPPED accumulators (see header):
@@ -401,6 +474,11 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
           }
         }
       }
+    }
+    // row statistics AFTER the sub-tile's global stores have been issued: the
+    // VALU work then runs while the stores drain
+    if constexpr (EPI == MDLM_EPI_STORE && BF16_OUT) {
+      if (g.lse_part) lse_partials<MT, M0, MS>(accf, grow0, gcol0, ec, g, lane);   // wave-uniform
     }
   }
 #undef acc
@@ -711,7 +789,8 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
                               const float* rot_cos, const float* rot_sin,
                               int n_heads, const int32_t* m_rows_dev,
                               const int32_t* out_sample_map,
-                              const int32_t* out_row_map, int tile, void* stream) {
+                              const int32_t* out_row_map, float* lse_partials_out,
+                              int lse_skip_col, int tile, void* stream) {
   if (M == 0) return 0;
   MDLM_CHECK_ARG(A && W && C, "gemm_bf16: null pointer");
   MDLM_CHECK_ARG((tile & ~7) == 0, "gemm_bf16: tile must be 0 (auto) or 1 (128x128)");
@@ -732,6 +811,11 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
   g.tiles_m = 0; g.tiles_n = 0; g.dbg = tile & 6;   // ablation builds only
   tile &= 1;
   g.ldw = K; g.splits = 1; g.c_split_stride = 0; g.aux = nullptr;
+  g.lse_part = reinterpret_cast<float2*>(lse_partials_out); g.lse_skip = lse_skip_col;
+  g.lse_ng = (N + 63) / 64;
+  MDLM_CHECK_ARG(!lse_partials_out || (epilogue == MDLM_EPI_STORE && dtype_c == MDLM_BF16 &&
+                                       ((uintptr_t)lse_partials_out & 7) == 0 && M % 256 == 0),
+                 "gemm_bf16: lse partials need the bf16 STORE epilogue, M %% 256 == 0 and an 8-byte aligned buffer");
   hipStream_t s = (hipStream_t)stream;
   // 16-byte row stores: 8 bf16 or 4 fp32 per lane
   const int64_t per16 = dtype_c == MDLM_F32 ? 4 : 8;
@@ -808,6 +892,7 @@ extern "C" int mdlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
   g.out_sample_map = nullptr; g.out_row_map = nullptr; g.rot_cos = nullptr; g.rot_sin = nullptr;
   g.n_heads = 0; g.m_rows_dev = nullptr; g.tiles_m = 0; g.tiles_n = 0; g.dbg = 0;
   g.splits = splits; g.c_split_stride = M * (int64_t)N; g.vec_ok = 1; g.aux = nullptr;
+  g.lse_part = nullptr; g.lse_skip = -1; g.lse_ng = 0;
   return launch_gemm<MDLM_EPI_STORE, float>(g, (hipStream_t)stream);
 }
 
@@ -846,6 +931,67 @@ extern "C" int mdlm_gemm_bf16_gelu(const void* A, int64_t lda, const void* W, co
   g.rot_cos = nullptr; g.rot_sin = nullptr; g.n_heads = 0; g.m_rows_dev = nullptr;
   g.tiles_m = 0; g.tiles_n = 0; g.dbg = 0; g.splits = 1; g.c_split_stride = 0; g.vec_ok = 1;
   g.aux = aux;
+  g.lse_part = nullptr; g.lse_skip = -1; g.lse_ng = 0;
   if (mode == 0) return launch_gemm<EPI_BIAS_GELU_SAVE, bf16_t>(g, (hipStream_t)stream);
   return launch_gemm<EPI_MUL_GELU_GRAD, bf16_t>(g, (hipStream_t)stream);
+}
+
+
+// ---- row lse from the vocabulary GEMM's partials ------------------------------
+// One workgroup = 64 rows x 16 group slices: thread (slice, row) folds its share
+// of the row's ceil(N/64) (max, sum) pairs, the 16 slices meet in LDS, and
+// lse[out_row_map[row]] = max + ln(sum) (natural log, what mdlm_subs_ddpm_update
+// reads).  Loads are 512 contiguous bytes per wave.
+namespace mdlm {
+__global__ __launch_bounds__(1024) void lse_combine_kernel(
+    const float2* __restrict__ part, int ng, const int32_t* __restrict__ out_row_map,
+    const int32_t* __restrict__ n_rows_dev, int64_t rows, float* __restrict__ lse) {
+  __shared__ float sm_m[16][64], sm_s[16][64];
+  constexpr float L2E = 1.4426950408889634f;
+  const int rl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t R = (int64_t)blockIdx.x * 64 + rl;
+  const int64_t live = n_rows_dev ? (int64_t)*n_rows_dev : rows;
+  if ((int64_t)blockIdx.x * 64 >= live) return;   // block-uniform
+  const float2* p = part + (R >> 8) * (int64_t)ng * 256 + (R & 255);
+  float m = -INFINITY, s = 0.f;
+  for (int gq = sl; gq < ng; gq += 16) {
+    const float2 v = p[(int64_t)gq * 256];
+    const float M = fmaxf(m, v.x);
+    const float ea = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m - M) * L2E);
+    const float eb = (v.x == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((v.x - M) * L2E);
+    s = s * ea + v.y * eb;
+    m = M;
+  }
+  sm_m[sl][rl] = m; sm_s[sl][rl] = s;
+  __syncthreads();
+  if (sl == 0 && R < live && R < rows) {
+    float M = sm_m[0][rl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) M = fmaxf(M, sm_m[k][rl]);
+    float S = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      S += (sm_m[k][rl] == -INFINITY) ? 0.f : sm_s[k][rl] * __builtin_amdgcn_exp2f((sm_m[k][rl] - M) * L2E);
+    const int64_t dst = out_row_map ? (int64_t)out_row_map[R] : R;
+    if (dst >= 0) lse[dst] = M + logf(S);
+  }
+}
+}  // namespace mdlm
+
+extern "C" int64_t mdlm_gemm_lse_partials_workspace_bytes(int64_t M, int N) {
+  if (M < 0 || N <= 0 || M % 256) return -1;
+  return M * (int64_t)((N + 63) / 64) * 8;
+}
+
+extern "C" int mdlm_lse_combine(const float* partials, int64_t M, int N,
+                                const int32_t* out_row_map, const int32_t* n_rows_dev,
+                                float* lse, void* stream) {
+  if (M == 0) return 0;
+  MDLM_CHECK_ARG(partials && lse, "lse_combine: null pointer");
+  MDLM_CHECK_ARG(M > 0 && M % 256 == 0 && N > 0 && M / 64 < (1ll << 31), "lse_combine: M must be a positive multiple of 256");
+  MDLM_CHECK_ARG(((uintptr_t)partials & 7) == 0, "lse_combine: partials must be 8-byte aligned");
+  lse_combine_kernel<<<(unsigned)(M / 64), 1024, 0, (hipStream_t)stream>>>(
+    reinterpret_cast<const float2*>(partials), (N + 63) / 64, out_row_map, n_rows_dev, M, lse);
+  MDLM_LAUNCH_CHECK();
+  return 0;
 }

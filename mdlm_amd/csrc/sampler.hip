@@ -46,13 +46,27 @@ __device__ __forceinline__ void row_visit(const T* row, int V, FV&& fv, FS&& fs)
   for (int i = threadIdx.x; i < head; i += NT) fs(i, elem<T>::load(row + i));
   const int nvec = (V - head) / EPV;
   const uint4* vp = reinterpret_cast<const uint4*>(row + head);
-  for (int i = threadIdx.x; i < nvec; i += NT) {
+  // four 16-byte loads in flight per thread: inside the update kernel (few
+  // resident waves) one load per round trip left this pass latency-bound
+  int i = threadIdx.x;
+  for (; i + 3 * NT < nvec; i += 4 * NT) {
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = vp[i + k * NT];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float f[EPV];
+      unpack<T>(v[k], f);
+      fv(head + (i + k * NT) * EPV, f);
+    }
+  }
+  for (; i < nvec; i += NT) {
     float f[EPV];
     unpack<T>(vp[i], f);
     fv(head + i * EPV, f);
   }
-  for (int i = head + nvec * EPV + threadIdx.x; i < V; i += NT)
-    fs(i, elem<T>::load(row + i));
+  for (int j = head + nvec * EPV + threadIdx.x; j < V; j += NT)
+    fs(j, elem<T>::load(row + j));
 }
 
 struct LseState {
@@ -61,13 +75,27 @@ struct LseState {
     if (x > m) { s = s * __expf(m - x); m = x; }
     s += __expf(x - m);
   }
+  // N elements at once (N even): max by v_max3, exp2(x log2e - m log2e) with one
+  // packed fma per pair, packed adds -- 3.5 VALU instructions per element instead
+  // of 6 (the pass is VALU-bound: the row is L2-warm or streams at a fraction of
+  // the VALU time)
   template <int N> __device__ __forceinline__ void addv(const float (&x)[N]) {
-    float vm = x[0];
+    static_assert(N % 2 == 0, "pairs");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr float L2E = 1.4426950408889634f;
+    float vm = fmaxf(x[0], x[1]);
 #pragma unroll
-    for (int k = 1; k < N; ++k) vm = fmaxf(vm, x[k]);
-    if (vm > m) { s = s * __expf(m - vm); m = vm; }
+    for (int k = 2; k < N; k += 2) vm = fmaxf(fmaxf(vm, x[k]), x[k + 1]);
+    if (vm > m) { s = s * __builtin_amdgcn_exp2f((m - vm) * L2E); m = vm; }
+    const float nm = m == -INFINITY ? 0.f : -m * L2E;   // a row of -inf so far adds exp2(-inf) = 0
+    const f32x2 l2 = {L2E, L2E}, nm2 = {nm, nm};
+    f32x2 acc = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < N; ++k) s += __expf(x[k] - m);
+    for (int k = 0; k < N; k += 2) {
+      const f32x2 t = __builtin_elementwise_fma((f32x2){x[k], x[k + 1]}, l2, nm2);
+      acc += (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    }
+    s += acc.x + acc.y;
   }
 };
 

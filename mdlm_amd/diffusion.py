@@ -391,12 +391,17 @@ class Diffusion(_Base):
       if self._profile is not None:
         self._profile['rows'].append((st['n_rows'].clone(), st['n_mrows'].clone()
                                       if row_map is not None else st['n_rows'].clone()))
+      # row lse of the refreshed rows: out of the vocabulary GEMM's epilogue
+      # when only the masked rows are projected, else inside the
+      # update kernel (`fresh` flags); a separate pass only when asked for
+      lse_gemm = row_map is not None and self.config.sampling.get('lse_from_gemm', True)
       self.backbone.run(x, st['zeros'], st['cache'], sigma_is_zero=True,
                         active=st['active'], n_active_dev=st['n_active'],
-                        n_rows_dev=st['n_rows'], n_max=B, row_map=row_map)
-      # the row lse of the refreshed samples is computed inside the update
-      # kernel (`fresh` flags); a separate pass only when asked for
-      if want_lse:
+                        n_rows_dev=st['n_rows'], n_max=B, row_map=row_map,
+                        lse_out=st['lse'] if lse_gemm else None,
+                        lse_skip_col=self.mask_index)
+      st['lse_ready'] = lse_gemm
+      if want_lse and not lse_gemm:
         ops.subs_row_lse(st['cache'], x, self.mask_index, out=st['lse'],
                          sample_map=st['active'], L=Lq, n_rows_dev=st['n_rows'])
     else:
@@ -406,6 +411,7 @@ class Diffusion(_Base):
       self.backbone.run(x, sg, st['cache'],
                         sigma_is_zero=not self.time_conditioning)
       st['fresh'].fill_(1)
+      st['lse_ready'] = False
 
   def _fused_step(self, st, x, x_next, t_vec, dt, sigma=None):
     self._refresh_cache(st, x, sigma)
@@ -417,7 +423,8 @@ class Diffusion(_Base):
     # algorithmic bytes of the update: masked rows x V bf16 logits
     bb._timed('update', n_masked, 2.0 * self.vocab_size, lambda: ops.subs_ddpm_update(
       st['cache'], st['lse'], x, t_vec, dt, self.mask_index, seed=seed,
-      offset=off, changed=st['changed'], x_next=x_next, fresh=st['fresh'],
+      offset=off, changed=st['changed'], x_next=x_next,
+      fresh=None if st.get('lse_ready') else st['fresh'],
       fast_math=bool(self.config.sampling.get('fast_math', False)),
       n_exact=st['n_exact']))
 

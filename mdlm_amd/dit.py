@@ -233,7 +233,7 @@ class DIT(nn.Module):
 
   def run(self, indices, sigma, logits_out, sigma_is_zero=False, active=None,
           n_active_dev=None, n_rows_dev=None, n_max=None, row_map=None,
-          hidden_out=None):
+          hidden_out=None, lse_out=None, lse_skip_col=-1):
     """Run the backbone.  `indices` (B, L) int64.  `logits_out`: (B, L, V)
     bf16/fp32 view (padded leading dimension allowed).  If `active` (int32
     device list) is given, only the listed samples are evaluated (compacted
@@ -245,7 +245,10 @@ class DIT(nn.Module):
     `hidden_out` (B*L, D) fp32: stop after the last block and write the
     residual stream of the evaluated samples to their rows of this per-sample
     cache instead of projecting to the vocabulary (`project_rows` does that
-    later for the rows that need it)."""
+    later for the rows that need it).  `lse_out` (B*L) fp32 with a row map:
+    the SUBS row lse (column `lse_skip_col` = the mask token excluded) of the
+    projected rows comes out of the vocabulary GEMM's epilogue and is written to
+    lse_out[scatter[row]] -- no pass over the logits."""
     B, L = indices.shape
     p = self._prepare(L)
     D, H = self.hidden, self.n_heads
@@ -275,6 +278,16 @@ class DIT(nn.Module):
     # final layer are row-wise, so they run on the gathered masked rows only.
     tail_rows = (row_map is not None and n_mod == 1 and hidden_out is None
                  and getattr(self, 'tail_rows', True))
+    # SUBS row lse of the projected rows out of the vocabulary GEMM's epilogue
+    lsep = None
+    if lse_out is not None:
+      if row_map is None or M % 256:
+        raise ValueError('lse_out needs a masked-row map and a row count % 256 == 0')
+      if ws.get('lsep') is None or ws['lsep_key'] != (M, V):
+        ws['lsep'] = torch.empty(ops.workspace_bytes('gemm_lse_partials', M, V) // 4,
+                                 dtype=torch.float32, device=x.device)
+        ws['lsep_key'] = (M, V)
+      lsep = ws['lsep']
     n_blocks = len(p['blocks'])
     for bi, (bp, mod) in enumerate(zip(p['blocks'], mods)):
       # chunk order dit.py:249-250: shift_msa, scale_msa, gate_msa, shift_mlp,
@@ -308,7 +321,11 @@ class DIT(nn.Module):
           xm, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, 1, ld2, live))
         T('gemm_vocab', lt, GEMM * V, lambda: ops.gemm_bf16(
           h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
-          m_rows_dev=live, out_row_map=scatter, ldc=logits_out.stride(-2), M=M))
+          m_rows_dev=live, out_row_map=scatter, ldc=logits_out.stride(-2), M=M,
+          lse_partials=lsep, lse_skip_col=lse_skip_col))
+        if lsep is not None:
+          T('lse_combine', lt, 8.0 * ((V + 63) // 64), lambda: ops.lse_combine(
+            lsep, M, V, lse_out, out_row_map=scatter, n_rows_dev=live))
         return logits_out
       T('gemm_out', rows_t, GEMM * D, lambda: ops.gemm_bf16(
         ao, bp['out'], x, EPI_GATE_RESIDUAL, gate=mod[:, 2 * D:3 * D],
@@ -336,7 +353,11 @@ class DIT(nn.Module):
         n_rows_dev=live, row_gather=gather, rows=M))
       T('gemm_vocab', lt, GEMM * V, lambda: ops.gemm_bf16(
         h, p['final']['w'], logits_out, EPI_STORE, bias=p['final']['b'],
-        m_rows_dev=live, out_row_map=scatter, ldc=logits_out.stride(-2), M=M))
+        m_rows_dev=live, out_row_map=scatter, ldc=logits_out.stride(-2), M=M,
+        lse_partials=lsep, lse_skip_col=lse_skip_col))
+      if lsep is not None:
+        T('lse_combine', lt, 8.0 * ((V + 63) // 64), lambda: ops.lse_combine(
+          lsep, M, V, lse_out, out_row_map=scatter, n_rows_dev=live))
     else:
       T('ln_modulate', rows_t, LN_B, lambda: ops.ln_modulate(
         x, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, n_mod, ld2, n_rows_dev))

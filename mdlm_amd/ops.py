@@ -346,7 +346,8 @@ def ln_modulate(x, ln_w, shift, scale, out, rows_per_mod, n_mod=1, mod_ld=0,
 def gemm_bf16(A, W, C, epilogue=_lib.EPI_STORE, bias=None, gate=None,
               residual=None, rows_per_mod=1, n_mod=1, mod_ld=0, rot_cos=None,
               rot_sin=None, n_heads=0, m_rows_dev=None, out_sample_map=None,
-              out_row_map=None, ldc=None, M=None, tile=None):
+              out_row_map=None, ldc=None, M=None, tile=None, lse_partials=None,
+              lse_skip_col=-1):
   """C = epilogue(A @ W^T); see include/mdlm_hip.h (mdlm_gemm_bf16).  tile: 0 =
   the library chooses, 1 = 128x128 (None: DEFAULT_GEMM_TILE)."""
   if tile is None:
@@ -363,8 +364,16 @@ def gemm_bf16(A, W, C, epilogue=_lib.EPI_STORE, bias=None, gate=None,
        C.data_ptr(), int(ldc), _DT[C.dtype], int(M), N, K, int(epilogue),
        _p(gate), _p(residual), int(rows_per_mod), int(n_mod), int(mod_ld),
        _p(rot_cos), _p(rot_sin), int(n_heads), _p(m_rows_dev),
-       _p(out_sample_map), _p(out_row_map), int(tile), _stream())
+       _p(out_sample_map), _p(out_row_map), _p(lse_partials), int(lse_skip_col),
+       int(tile), _stream())
   return C
+
+
+def lse_combine(partials, M, N, lse, out_row_map=None, n_rows_dev=None):
+  """Row lse from the partials of gemm_bf16(..., lse_partials=...)."""
+  call('mdlm_lse_combine', partials.data_ptr(), int(M), int(N), _p(out_row_map),
+       _p(n_rows_dev), lse.data_ptr(), _stream())
+  return lse
 
 
 def splitk_plan(M, N, K_total, target_tiles=512, min_k=512):

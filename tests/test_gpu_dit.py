@@ -328,3 +328,41 @@ def test_dit_active_compaction_is_batch_invariant(ops):
   for b in (4, 1, 2):
     assert torch.equal(cache[b], full[b])
   assert (cache[0] == 0).all() and (cache[3] == 0).all()
+
+
+@pytest.mark.parametrize('N,mask', [(50258, 50257), (30522, 103), (1000, 999)])
+def test_vocab_gemm_row_lse_from_epilogue(ops, N, mask):
+  """the SUBS row statistics (diffusion.py:263-268) come out of
+  the vocabulary GEMM's epilogue (dit.py:317-321) as (max, sum exp) pairs per
+  64-column group; mdlm_lse_combine folds them.  Must equal the row lse of the
+  STORED bf16 logits (mask column shifted by -1e6, i.e. excluded) to 1e-5, for
+  the N-edge group (50258 = 785*64 + 18), a mask column inside the vocabulary
+  (bert: 103) and a scattered / partly dropped row list."""
+  torch.manual_seed(2)
+  from mdlm_amd._lib import EPI_STORE
+  M, K = 512, 256
+  A = _bf(torch.randn(M, K) * 2).cuda()
+  W = _bf(torch.randn(N, K) * 0.3).cuda()
+  b = torch.randn(N).cuda()
+  rows_out = 700
+  perm = torch.randperm(rows_out)[:M].to(torch.int32)
+  perm[5] = -1; perm[300:310] = -1          # dropped rows (padding of the row list)
+  scatter = perm.cuda()
+  live = torch.tensor([M], dtype=torch.int32).cuda()
+  logits = torch.zeros(rows_out, ops.padded_vocab(N), dtype=torch.bfloat16).cuda()
+  part = torch.empty(ops.workspace_bytes('gemm_lse_partials', M, N) // 4).cuda()
+  lse = torch.full((rows_out,), float('nan')).cuda()
+  ops.gemm_bf16(A, W, logits, EPI_STORE, bias=b, out_row_map=scatter, m_rows_dev=live,
+                ldc=logits.stride(0), lse_partials=part, lse_skip_col=mask)
+  ops.lse_combine(part, M, N, lse, out_row_map=scatter, n_rows_dev=live)
+  lg = logits[:, :N].float()
+  lg[:, mask] = float('-inf')
+  ref = torch.logsumexp(lg, -1)
+  kept = perm[perm >= 0].long()
+  assert (lse[kept] - ref[kept]).abs().max().item() < 1e-5
+  rest = torch.ones(rows_out, dtype=torch.bool); rest[kept] = False
+  assert torch.isnan(lse[rest.cuda()]).all()   # rows not in the list are not touched
+  # and against the stand-alone kernel on the same stored logits
+  x = torch.full((rows_out, 1), mask, dtype=torch.int64).cuda()
+  lse2 = ops.subs_row_lse(logits[:, None, :N], x, mask)
+  assert (lse[kept] - lse2.view(-1)[kept]).abs().max().item() < 1e-5

@@ -54,7 +54,7 @@ def test_argument_errors_do_not_need_a_gpu():
     _lib.call('mdlm_subs_logprobs', 0, 8, 0, 0, 0, 8, 0, 1, 8, 7, 0, 0)
   with pytest.raises(RuntimeError, match='multiple of 128'):
     _lib.call('mdlm_gemm_bf16', 16, 64, 16, 0, 16, 64, 1, 100, 64, 64, 0, 0, 0, 1, 1, 0,
-              0, 0, 0, 0, 0, 0, 0, 0)
+              0, 0, 0, 0, 0, 0, 0, -1, 0, 0)
   with pytest.raises(RuntimeError, match='multiple of'):
     _lib.call('mdlm_attn_fwd', 16, 16, 16, 16, 1, 1, 100, 0, 0)
 
