@@ -8,11 +8,10 @@ for path in sys.argv[1:3]:
   l = C.CDLL(path)
   l.mdlm_gemm_bf16.restype = C.c_int
   l.mdlm_gemm_bf16.argtypes = SIGNATURES['mdlm_gemm_bf16']
-  l.mdlm_gemm_set_tile.argtypes = [C.c_int]
   libs.append(l)
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-for l in libs: l.mdlm_gemm_set_tile(mode)
+only = sys.argv[5].split(',') if len(sys.argv) > 5 else None
 torch.manual_seed(0)
 L, D, V = 1024, 768, 50258
 dev = 'cuda'
@@ -29,7 +28,7 @@ mod = torch.randn(1, 6 * D, device=dev); cos = torch.randn(L, 32, device=dev); s
 P = lambda t: t.data_ptr() if t is not None else 0
 st = torch.cuda.current_stream().cuda_stream
 def call(l, A, lda, W, bias, Cc, ldc, dt, N, K, epi, gate=None, res=None, rpm=L, nmod=1, modld=6 * D, rc=None, rs=None, nh=0):
-  rc_ = l.mdlm_gemm_bf16(P(A), lda, P(W), P(bias), P(Cc), ldc, dt, M, N, K, epi, P(gate), P(res), rpm, nmod, modld, P(rc), P(rs), nh, 0, 0, 0, st)
+  rc_ = l.mdlm_gemm_bf16(P(A), lda, P(W), P(bias), P(Cc), ldc, dt, M, N, K, epi, P(gate), P(res), rpm, nmod, modld, P(rc), P(rs), nh, 0, 0, 0, 0, -1, mode, st)
   assert rc_ == 0
 shapes = {
   'qkv': lambda l: call(l, h, D, Wqkv, None, qkv, 0, 1, 3 * D, D, EPI_QKV_ROTARY, rc=cos, rs=sin, nh=12),
@@ -46,6 +45,7 @@ def tm(fn, l, iters):
   e1.record(); torch.cuda.synchronize()
   return e0.elapsed_time(e1) / iters * 1e3
 for name, fn in shapes.items():
+  if only and name not in only: continue
   it = 4 if name == 'vocab' else 20
   for l in libs: tm(fn, l, 3)
   res = [[], []]

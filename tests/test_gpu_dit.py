@@ -232,6 +232,33 @@ def test_attention(ops, L):
   assert torch.equal(out2[:L], out[:L]) and (out2[L:] == 9).all()
 
 
+@pytest.mark.parametrize('L', [128, 256, 1024])
+def test_attention_scale_guard(ops, L):
+  """The kernels keep the first key block's max as the softmax scale and only
+  re-scale when a row sum overflows.  Scores that grow along the sequence by far
+  more than fp32's exponent range (~2^450 in the exp2 domain here) force that
+  path repeatedly; rows that see only tiny or hugely negative scores afterwards
+  exercise the other direction.  Against SDPA in fp32 on the same bf16 inputs
+  (flash-attn semantics, dit.py:265-275)."""
+  torch.manual_seed(8)
+  B, H = 1, 2
+  q = torch.randn(B, H, L, 64); k = torch.randn(B, H, L, 64); v = torch.randn(B, H, L, 64)
+  ramp = torch.linspace(0, 1, L)[None, :, None]
+  k[0, 0] = k[0, 0] * 0.1 + q[0, 0, :1] * ramp[0] * 16.0     # head 0: scores rise steadily for query 0
+  k[0, 1] = k[0, 1] * 0.1 - q[0, 1, 3:4] * ramp[0] * 16.0    # head 1: scores fall for query 3
+  qb, kb, vb = _bf(q), _bf(k), _bf(v)
+  s = (qb.float() @ kb.float().transpose(-1, -2)) * 0.125 * 1.4426950408889634
+  assert (s.max(-1).values - s[..., 0]).max().item() > 150     # far beyond the 2^100 guard
+  ref = F.scaled_dot_product_attention(qb.float(), kb.float(), vb.float())
+  ref = ref.transpose(1, 2).reshape(B * L, H * 64)
+  out = torch.zeros(B * L, H * 64, dtype=torch.bfloat16, device='cuda')
+  ops.attn_fwd(qb.cuda(), kb.cuda(), vb.transpose(2, 3).contiguous().cuda(), out, B, H, L)
+  err = (out.float().cpu() - ref).abs()
+  assert torch.isfinite(out.float()).all()
+  assert err.max().item() < 3e-2, err.max().item()
+  assert _rel(out.float().cpu(), ref) < 1e-2
+
+
 def _make_model(hidden, heads, blocks, cond, V, seed):
   from mdlm_amd.dit import DIT
   cfg = {'model': dict(hidden_size=hidden, cond_dim=cond, n_heads=heads,
