@@ -308,8 +308,9 @@ KERNELS = {
   'gemm_fc1': ('gemm_bf16_kernel<EPI_BIAS_GELU,bf16> mlp.0 768->3072', 'mfma'),
   'gemm_qkv': ('gemm_bf16_kernel<EPI_QKV_ROTARY,bf16> 768->2304 + rotary', 'mfma'),
   'gemm_vocab': ('gemm_bf16_kernel<EPI_STORE,bf16> vocab projection 768->V, masked rows', 'mfma'),
-  'attention': ('attn_fwd_kernel', 'mfma'),
+  'attention': ('attn_fwd_pipe_kernel', 'mfma'),
   'update': ('ddpm_update_fast_kernel (SUBS + race fused from logits)', 'hbm'),
+  'lse_combine': ('lse_combine_kernel', 'hbm'),
   'ln_modulate': ('ln_modulate_kernel', 'hbm'),
   'embed': ('embed_rows_kernel', 'hbm'),
   'gather_rows': ('gather_rows_kernel', 'hbm'),
@@ -317,10 +318,6 @@ KERNELS = {
   'gemm_gate_residual': ('gemm_bf16_kernel<EPI_GATE_RESIDUAL,fp32,256x256> (attn_out 768->768 and '
                          'mlp.2 3072->768: one symbol in the rocprof trace)', 'mfma'),
 }
-# tag -> key of profiles/pmc_traffic.json (tools/pmc_traffic.py)
-PMC_TAGS = {'gemm_gate_residual': 'gate_residual', 'gemm_fc1': 'mlp_up_gelu',
-            'gemm_qkv': 'qkv_rotary', 'gemm_vocab': 'vocab', 'attention': 'attention',
-            'update': 'ddpm_update', 'ln_modulate': 'ln_modulate'}
 
 
 def kernel_rooflines(events, traffic):
@@ -361,8 +358,9 @@ def kernel_rooflines(events, traffic):
       d.update(achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                frac=round(ach / PEAK_HBM_GBS, 4),
                algorithmic_mbytes_per_launch=round(work / n / 1e6, 2))
-    tr = traffic.get(PMC_TAGS.get(tag))
-    d['traffic'] = (round(tr['hbm_bytes_per_launch'] / traffic['_rows_per_launch_profiled']
+    tr = traffic.get(tag)   # keys of profiles/pmc_traffic.json = these tags (tools/pmc_traffic.py)
+    d['traffic'] = (round(tr['hbm_bytes_per_launch']
+                          / tr.get('rows_per_launch', traffic['_rows_per_launch_profiled'])
                           * sum(rows) / n) if tr else None)
     if tr:
       d['traffic_unit'] = ('HBM bytes/launch: PMC FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 '

@@ -16,10 +16,12 @@ import json
 import os
 import sys
 
-TAGS = {'gate_residual': 'gemm_bf16_kernel<2,', 'vocab': 'gemm_bf16_kernel<0, unsigned short',
-        'mlp_up_gelu': 'gemm_bf16_kernel<1,', 'qkv_rotary': 'gemm_bf16_kernel<3,',
-        'attention': 'attn_fwd_kernel', 'ddpm_update': 'ddpm_update_fast_kernel',
-        'ln_modulate': 'ln_modulate_kernel'}
+# bench.py's roofline tags -> substring of the kernel symbol in the trace
+TAGS = {'gemm_gate_residual': 'gemm_bf16_kernel<2,', 'gemm_vocab': 'gemm_bf16_kernel<0, unsigned short',
+        'gemm_fc1': 'gemm_bf16_kernel<1,', 'gemm_qkv': 'gemm_bf16_kernel<3,',
+        'attention': 'attn_fwd_pipe_kernel', 'update': 'ddpm_update_fast_kernel',
+        'ln_modulate': 'ln_modulate_kernel', 'lse_combine': 'lse_combine_kernel',
+        'embed': 'embed_rows_kernel', 'gather_rows': 'gather_rows_kernel'}
 
 
 def collect(d, counter):
@@ -46,6 +48,22 @@ def main():
       res[tag] = {'hbm_bytes_per_launch': round(fetch + write), 'fetch_bytes': round(fetch),
                   'write_bytes': round(write), 'launches_profiled': fe[tag][1],
                   'note': 'FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes'}
+  res['_collected'] = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py '
+                       '--steps 1 --warmup 0 --T 100 --no-eval --no-cpu-baseline --no-policy-compare '
+                       '--profile-stride 0 (tools/pmc_run.sh); at T=100 every sample changes each step, so '
+                       'every backbone launch is full size (65,536 rows); bench.py scales bytes/row to its own '
+                       'average rows per launch (the vocabulary GEMM, the update and the row kernels run on the '
+                       'masked rows: their per-launch row count is taken from the same run)')
+  res['_rows_per_launch_profiled'] = 65536
+  # kernels that run on the masked rows only: their average row count in this run
+  # follows from the vocabulary GEMM's written bytes (V bf16 logits + one float2
+  # per 64-column group for every row)
+  V = 50258
+  if 'gemm_vocab' in res:
+    rows_m = res['gemm_vocab']['write_bytes'] / (V * 2 + ((V + 63) // 64) * 8)
+    for tag in ('gemm_vocab', 'update', 'lse_combine', 'gather_rows'):
+      if tag in res:
+        res[tag]['rows_per_launch'] = round(rows_m)
   json.dump(res, open(out, 'w'), indent=1)
   print(json.dumps(res))
 
