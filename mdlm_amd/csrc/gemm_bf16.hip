@@ -762,7 +762,10 @@ static int launch_cfg(GemmArgs g, hipStream_t s) {
   if (grid >= (1ll << 31)) { set_error("gemm: grid too large"); return -1; }
   // persistent launch: one workgroup per CU for the 128 KiB-LDS tile, two for
   // the 64 KiB one
-  const int64_t resident = (LDS > 80 * 1024) ? 256 : 512;
+  int64_t resident = (LDS > 80 * 1024) ? 256 : 512;
+#ifdef MDLM_GEMM_ABLATION
+  if (g.dbg & 8) resident /= 2;   // experiment: half of the CUs
+#endif
   if (grid > resident) grid = resident;
   gemm_bf16_kernel<EPI, TC, WM, WN, MT><<<(unsigned)grid, 64 * WM * WN, LDS, s>>>(g);
   MDLM_LAUNCH_CHECK();
@@ -793,7 +796,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
                               int lse_skip_col, int tile, void* stream) {
   if (M == 0) return 0;
   MDLM_CHECK_ARG(A && W && C, "gemm_bf16: null pointer");
-  MDLM_CHECK_ARG((tile & ~7) == 0, "gemm_bf16: tile must be 0 (auto) or 1 (128x128)");
+  MDLM_CHECK_ARG((tile & ~15) == 0, "gemm_bf16: tile must be 0 (auto) or 1 (128x128)");
   MDLM_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_bf16: bad shape");
   MDLM_CHECK_ARG(M % 128 == 0, "gemm_bf16: M=%lld must be a multiple of 128", (long long)M);
   MDLM_CHECK_ARG(K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d", K, BK);
@@ -808,7 +811,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
   g.rows_per_mod = rows_per_mod > 0 ? rows_per_mod : 1; g.n_mod = n_mod > 0 ? n_mod : 1;
   g.mod_ld = mod_ld; g.out_sample_map = out_sample_map; g.out_row_map = out_row_map;
   g.rot_cos = rot_cos; g.rot_sin = rot_sin; g.n_heads = n_heads; g.m_rows_dev = m_rows_dev;
-  g.tiles_m = 0; g.tiles_n = 0; g.dbg = tile & 6;   // ablation builds only
+  g.tiles_m = 0; g.tiles_n = 0; g.dbg = tile & 14;   // ablation builds only
   tile &= 1;
   g.ldw = K; g.splits = 1; g.c_split_stride = 0; g.aux = nullptr;
   g.lse_part = reinterpret_cast<float2*>(lse_partials_out); g.lse_skip = lse_skip_col;
