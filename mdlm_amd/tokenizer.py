@@ -25,13 +25,39 @@ class SyntheticTokenizer:
     return [self.decode(row) for row in batch]
 
 
+def _finish_tokenizer(tokenizer):
+  """The post-processing of dataloader.py:497-520: GPT-2 tokenizers wrap every
+  sentence in [BOS] ... [EOS]; bos / eos fall back to cls / sep; a pad token is
+  added when there is none."""
+  import tokenizers
+  import transformers
+  gpt2 = tuple(c for c in (getattr(transformers, 'GPT2TokenizerFast', None),
+                           getattr(transformers, 'GPT2Tokenizer', None)) if c is not None)
+  if gpt2 and isinstance(tokenizer, gpt2):
+    tokenizer._tokenizer.post_processor = tokenizers.processors.BertProcessing(
+      (tokenizer.bos_token, tokenizer.bos_token_id),
+      (tokenizer.eos_token, tokenizer.eos_token_id))
+  if tokenizer.bos_token is None:
+    if tokenizer.cls_token is None:
+      raise AttributeError(f'Tokenizer must have a bos_token or cls_token: {tokenizer}')
+    tokenizer.bos_token = tokenizer.cls_token
+  if tokenizer.eos_token is None:
+    if tokenizer.sep_token is None:
+      raise AttributeError(f'Tokenizer must have a eos_token or sep_token: {tokenizer}')
+    tokenizer.eos_token = tokenizer.sep_token
+  if tokenizer.pad_token is None:
+    tokenizer.add_special_tokens({'pad_token': '[PAD]'})
+  return tokenizer
+
+
 def get_tokenizer(config):
   """A local tokenizer directory is loaded with transformers; anything else
   (hub names cannot be fetched offline) yields the synthetic stand-in."""
   path = config.data.tokenizer_name_or_path
   if isinstance(path, str) and os.path.isdir(path):
     import transformers
-    return transformers.AutoTokenizer.from_pretrained(path)
+    tokenizer = transformers.AutoTokenizer.from_pretrained(path)
+    return _finish_tokenizer(tokenizer)
   if isinstance(path, str) and 'bert' in path:
     # bert-base-uncased contract (dataloader.py:488-522): [CLS]=101 as BOS,
     # [SEP]=102 as EOS, [PAD]=0, an in-vocabulary [MASK]=103

@@ -210,6 +210,42 @@ def test_semi_ar_matches_oracle(ops):
     assert int(seqlens[i]) == exp
 
 
+def test_semi_ar_with_a_real_local_tokenizer(ops, tmp_path):
+  """main.py:94-107 end to end with a REAL tokenizer loaded from a local
+  directory (dataloader.py:488-522; a byte-level BPE in the GPT-2 file format,
+  trained in the test because the hub is unreachable): mask_index = vocab_size
+  (diffusion.py:85-90), semi-AR sampling, `batch_decode` of the sampled ids and the
+  EOS-based sequence lengths (diffusion.py:989-995)."""
+  from test_host import _local_gpt2_style_tokenizer
+  from mdlm_amd.config import load_config
+  from mdlm_amd.diffusion import Diffusion
+  from mdlm_amd.tokenizer import get_tokenizer
+  d = str(tmp_path / 'tok')
+  _local_gpt2_style_tokenizer(d)
+  cfg = load_config(['model=tiny', 'loader.eval_batch_size=2', 'sampling.steps=8',
+                     f'data.tokenizer_name_or_path={d}'])
+  tok = get_tokenizer(cfg)
+  model = Diffusion(cfg, tok).cuda()
+  Vt = tok.vocab_size + 1
+  assert model.mask_index == tok.vocab_size and model.vocab_size == Vt
+  m = cfg.model
+  p = orc.synthetic_dit_params(m.hidden_size, m.n_heads, m.n_blocks, m.cond_dim, Vt, seed=4)
+  sd = dict(p); sd['rotary_emb.inv_freq'] = model.backbone.rotary_emb.inv_freq
+  model.backbone.load_state_dict(sd)
+  model.ema = None
+  L = m.length
+  steps, texts, seqlens = model.restore_model_and_semi_ar_sample(
+    stride_length=L // 2, num_strides=1, dt=1 / 8)
+  toks = model.last_tokens
+  assert toks.shape == (2, L + L // 2) and (toks != model.mask_index).all()
+  assert texts[-1] == tok.batch_decode(toks)           # the decoded text is the sampled ids'
+  assert all(isinstance(t, str) and len(t) > 0 for t in texts[-1])
+  eos = tok.eos_token_id
+  for i in range(2):
+    row = toks[i, 1:].tolist()
+    assert int(seqlens[i]) == (row.index(eos) if eos in row else len(row))
+
+
 def test_loss_matches_oracle(ops):
   model, cfg, p = make_model()
   B, L = 4, cfg.model.length

@@ -312,3 +312,49 @@ def test_bench_self_launch_two_gloo_ranks():
   assert len(lines) == 1
   d = json.loads(lines[0])['dist']
   assert d == {'backend': 'gloo', 'world_size': 2, 'allreduce_check': True}
+
+
+def _local_gpt2_style_tokenizer(path):
+  """A byte-level BPE tokenizer in the GPT-2 file format, trained here on a few
+  sentences (the hub is not reachable) and saved as a local directory."""
+  import tokenizers
+  import transformers
+  tk = tokenizers.Tokenizer(tokenizers.models.BPE())
+  tk.pre_tokenizer = tokenizers.pre_tokenizers.ByteLevel(add_prefix_space=False)
+  tk.decoder = tokenizers.decoders.ByteLevel()
+  trainer = tokenizers.trainers.BpeTrainer(
+    vocab_size=400, special_tokens=['<|endoftext|>'],
+    initial_alphabet=tokenizers.pre_tokenizers.ByteLevel.alphabet())
+  corpus = ['the quick brown fox jumps over the lazy dog',
+            'masked diffusion language models sample tokens in any order',
+            'a journey of a thousand miles begins with a single step'] * 4
+  tk.train_from_iterator(corpus, trainer)
+  fast = transformers.PreTrainedTokenizerFast(
+    tokenizer_object=tk, bos_token='<|endoftext|>', eos_token='<|endoftext|>',
+    unk_token='<|endoftext|>')
+  fast.save_pretrained(path)
+  return corpus
+
+
+def test_local_tokenizer_directory_roundtrip(tmp_path):
+  """dataloader.py:488-522 with a LOCAL tokenizer directory (hub names cannot be
+  fetched here): loading, the bos / eos / pad post-processing, the
+  mask_index = vocab_size rule of diffusion.py:85-90, `batch_decode` of sampled
+  ids (main.py:103-104) and the EOS-based `sequence_lengths` of
+  diffusion.py:989-992."""
+  from mdlm_amd.config import load_config
+  from mdlm_amd.tokenizer import get_tokenizer
+  d = str(tmp_path / 'tok')
+  corpus = _local_gpt2_style_tokenizer(d)
+  cfg = load_config([f'data.tokenizer_name_or_path={d}'])
+  tok = get_tokenizer(cfg)
+  assert tok.bos_token == tok.eos_token == '<|endoftext|>' and tok.pad_token == '[PAD]'
+  assert getattr(tok, 'mask_token', None) is None        # -> mask_index = vocab_size
+  ids = tok(corpus[:2])['input_ids']
+  assert tok.batch_decode(ids) == corpus[:2]             # exact round trip
+  # sequence_lengths: tokens before the first EOS after position 0 (989-992)
+  eos = tok.eos_token_id
+  toks = np.array([[eos] + ids[0][:5] + [eos] + ids[1][:3],
+                   [eos] + ids[1][:9]])
+  seq_len = ((toks[:, 1:] == eos).cumsum(-1) == 0).sum(-1)
+  assert seq_len.tolist() == [5, 9]
