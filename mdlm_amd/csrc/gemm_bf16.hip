@@ -525,10 +525,34 @@ void gemm_bf16_kernel(GemmArgs g) {
   const int per_xcd = (total + 7) >> 3;
   const int s_begin = xcd * per_xcd;
   const int s_end = total < s_begin + per_xcd ? total : s_begin + per_xcd;
-  // tile at index j of this XCD's range (-1: past its end)
-  auto next_tile = [&](int j, int& tm, int& tn, int& sp) -> int {
+  // Tail of an XCD's range.  Its `cnt` tiles run in rounds of `slots`
+  // workgroups; when the last round holds at most slots/2 tiles, each of them is
+  // cut into two half tiles of TBM/2 rows (same N, same K order per output row, so
+  // the results are bit-identical): the partial round then costs about half a
+  // round instead of a whole one.  (In the sampling loop the row count changes
+  // every step: 12 n tiles of the N = 768 GEMMs on 256 workgroups, n = 40 +- 6.)
+  // Only where it pays (same-process sweep over 30-54 active samples, scratch/sweep_half.py):
+  // gate/residual -4.5 % / -2.6 % (K = 768 / 3072), QKV -1.9 %; the GELU and plain-store
+  // instantiations sit at the 256-register limit and the second tile body spills them (+5 %).
+  constexpr bool HALF_OK = !SPLITK && MT == 8 &&
+                           (EPI == MDLM_EPI_GATE_RESIDUAL || EPI == MDLM_EPI_QKV_ROTARY);
+  const int cnt = s_end > s_begin ? s_end - s_begin : 0;
+  const int full_r = cnt / slots;
+  const int rx = cnt - full_r * slots;
+  const bool split_tail = HALF_OK && rx > 0 && 2 * rx <= slots;
+  const int n_full = split_tail ? full_r * slots : cnt;   // virtual indices below: whole tiles
+  const int n_virt = split_tail ? n_full + 2 * rx : cnt;
+  // tile at virtual index j of this XCD's range (-1: past its end); hf = -1 for a
+  // whole tile, 0 / 1 for its upper / lower half
+  auto next_tile = [&](int j, int& tm, int& tn, int& sp, int& hf) -> int {
+    if (j >= n_virt) return -1;
     int s = s_begin + j;
-    if (s >= s_end) return -1;
+    hf = -1;
+    if (j >= n_full) {
+      const int e = j - n_full;
+      s = s_begin + n_full + (e >> 1);
+      hf = e & 1;
+    }
     sp = 0;
     if constexpr (SPLITK) {   // split outermost: neighbours share the K range
       sp = s / per_split;
@@ -550,13 +574,18 @@ void gemm_bf16_kernel(GemmArgs g) {
   const int skc = ((lane & 7) ^ srow) * 8;  // element offset inside the 64-wide K slab
   const bf16_t* a_src[A_CH];
   const bf16_t* b_src[B_CH];
-  auto set_src = [&](int tm, int tn, int sp) {
-    const int64_t m0 = (int64_t)tm * TBM;
+  auto set_src = [&](int tm, int tn, int sp, int hf) {
+    // a half tile stages the TBM rows from ITS first row (it reads the first
+    // TBM/2 of them); rows past the matrix are clamped, never read
+    const int64_t m0 = (int64_t)tm * TBM + (hf == 1 ? TBM / 2 : 0);
     const int n0 = tn * TBN;
     const int64_t kofs = (SPLITK ? (int64_t)sp * g.K : 0) + skc;
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i)
-      a_src[i] = g.A + (m0 + (i * NW + wid) * 8 + srow) * g.lda + kofs;
+    for (int i = 0; i < A_CH; ++i) {
+      int64_t arow = m0 + (i * NW + wid) * 8 + srow;
+      arow = arow < g.M ? arow : g.M - 1;
+      a_src[i] = g.A + arow * g.lda + kofs;
+    }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       int brow = n0 + (i * NW + wid) * 8 + srow;
@@ -581,14 +610,13 @@ void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
     foff[ks] = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) * 16);
-  const int a_base = wr * (MT * 16) * 128;
   const int b_base = A_BYTES + wc * 64 * 128;
   const int KT = g.K / BK;
 
-  int tm, tn, sp;
-  int j = next_tile(bid >> 3, tm, tn, sp);
+  int tm, tn, sp, hf;
+  int j = next_tile(bid >> 3, tm, tn, sp, hf);
   if (j < 0) return;
-  set_src(tm, tn, sp);
+  set_src(tm, tn, sp, hf);
   stage(0, 0);
   int buf = 0;          // stage holding the slab the next K step reads
   // the LDS-DMA of this wave must have landed before any wave reads the stage:
@@ -597,11 +625,17 @@ void gemm_bf16_kernel(GemmArgs g) {
   __syncthreads();
 
   while (true) {
-    int tm_next, tn_next, sp_next;
-    const int j_next = next_tile(j + slots, tm_next, tn_next, sp_next);
-    const int64_t m0 = (int64_t)tm * TBM;
+    int tm_next, tn_next, sp_next, hf_next;
+    const int j_next = next_tile(j + slots, tm_next, tn_next, sp_next, hf_next);
+    const int64_t m0 = (int64_t)tm * TBM + (hf == 1 ? TBM / 2 : 0);
     const int n0 = tn * TBN;
     const int gcol0 = n0 + wc * 64;
+
+    // One tile: MTE = MT for a whole tile, MT / 2 for a half tile (each wave then
+    // owns MTE * 16 rows; the staged A block starts at the half tile's first row)
+    auto tile_body = [&](auto mte_c) {
+    constexpr int MTE = decltype(mte_c)::value;
+    const int a_base = wr * (MTE * 16) * 128;
 
     // ---- column constants of this wave tile (latency hidden by the K loop) --
     EpiConsts ec;
@@ -624,9 +658,9 @@ void gemm_bf16_kernel(GemmArgs g) {
           if (g.bias) ec.b4 = *reinterpret_cast<const float4*>(g.bias + gc);
           if constexpr (EPI == MDLM_EPI_GATE_RESIDUAL) {
             // one gate row for the whole wave tile unless samples are shorter than it
-            ec.gt_tile = g.n_mod == 1 || g.rows_per_mod % (MT * 16) == 0;
+            ec.gt_tile = g.n_mod == 1 || g.rows_per_mod % (MTE * 16) == 0;
             if (ec.gt_tile) {
-              const int64_t growW = m0 + wr * (MT * 16);
+              const int64_t growW = m0 + wr * (MTE * 16);
               const int64_t mrow = g.n_mod == 1 ? 0 : (growW / g.rows_per_mod) % g.n_mod;
               ec.gt = *reinterpret_cast<const float4*>(g.gate + mrow * g.mod_ld + gc);
             }
@@ -635,9 +669,9 @@ void gemm_bf16_kernel(GemmArgs g) {
       }
     }
 
-    f32x4 acc[MT][4];
+    f32x4 acc[MTE][4];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MTE; ++m)
 #pragma unroll
       for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -652,25 +686,25 @@ void gemm_bf16_kernel(GemmArgs g) {
         if (kt + 1 < KT) {
           stage(buf ^ 1, (kt + 1) * BK);
         } else if (j_next >= 0) {
-          set_src(tm_next, tn_next, sp_next);   // first slab of the next tile
+          set_src(tm_next, tn_next, sp_next, hf_next);   // first slab of the next tile
           stage(buf ^ 1, 0);
         }
         const char* At = smem + buf * STAGE + a_base;
         const char* Bt = smem + buf * STAGE + b_base;
-        bf16x8 af[2][MT], bfr[2][4];
+        bf16x8 af[2][MTE], bfr[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
           for (int n = 0; n < 4; ++n)
             bfr[ks][n] = *reinterpret_cast<const bf16x8*>(Bt + n * 2048 + foff[ks]);
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MTE; ++m)
             af[ks][m] = *reinterpret_cast<const bf16x8*>(At + m * 2048 + foff[ks]);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MTE; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
               if constexpr (NAT)
@@ -682,7 +716,7 @@ void gemm_bf16_kernel(GemmArgs g) {
         // reads up front, then one read behind every group of 4 MFMAs (same-
         // process A/B: 16 up front is 2-3 % faster for the bf16-output kernels,
         // 12 for the fp32 gate/residual one, whose K = 3072 shape loses 4 % at 16)
-        if constexpr (MT == 8) {
+        if constexpr (MTE == 8) {
           constexpr int R0 = BF16_OUT ? 16 : 12;
           __builtin_amdgcn_sched_group_barrier(0x100, R0, 0);
 #pragma unroll
@@ -712,32 +746,39 @@ void gemm_bf16_kernel(GemmArgs g) {
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
       char* ep = smem + (buf ^ 1) * STAGE + wid * 8192;
-      const int64_t growW = m0 + wr * (MT * 16);
+      const int64_t growW = m0 + wr * (MTE * 16);
       if constexpr (BF16_OUT) {
-        epilogue_sub<EPI, TC, MT, 0, 4>(acc, ep, growW, gcol0, ec, g, lane_e);
-        if constexpr (MT == 8) epilogue_sub<EPI, TC, MT, 4, 4>(acc, ep, growW + 64, gcol0, ec, g, lane_e);
+        epilogue_sub<EPI, TC, MTE, 0, 4>(acc, ep, growW, gcol0, ec, g, lane_e);
+        if constexpr (MTE == 8) epilogue_sub<EPI, TC, MTE, 4, 4>(acc, ep, growW + 64, gcol0, ec, g, lane_e);
       } else if constexpr (SPLITK) {
         GemmArgs gs = g;   // this split's partial-sum plane
         gs.C = reinterpret_cast<float*>(g.C) + (int64_t)sp * g.c_split_stride;
-        epilogue_sub<EPI, TC, MT, 0, 2>(acc, ep, growW, gcol0, ec, gs, lane_e);
-        epilogue_sub<EPI, TC, MT, 2, 2>(acc, ep, growW + 32, gcol0, ec, gs, lane_e);
-        if constexpr (MT == 8) {
-          epilogue_sub<EPI, TC, MT, 4, 2>(acc, ep, growW + 64, gcol0, ec, gs, lane_e);
-          epilogue_sub<EPI, TC, MT, 6, 2>(acc, ep, growW + 96, gcol0, ec, gs, lane_e);
+        epilogue_sub<EPI, TC, MTE, 0, 2>(acc, ep, growW, gcol0, ec, gs, lane_e);
+        epilogue_sub<EPI, TC, MTE, 2, 2>(acc, ep, growW + 32, gcol0, ec, gs, lane_e);
+        if constexpr (MTE == 8) {
+          epilogue_sub<EPI, TC, MTE, 4, 2>(acc, ep, growW + 64, gcol0, ec, gs, lane_e);
+          epilogue_sub<EPI, TC, MTE, 6, 2>(acc, ep, growW + 96, gcol0, ec, gs, lane_e);
         }
       } else {
-        epilogue_sub<EPI, TC, MT, 0, 2>(acc, ep, growW, gcol0, ec, g, lane_e);
-        epilogue_sub<EPI, TC, MT, 2, 2>(acc, ep, growW + 32, gcol0, ec, g, lane_e);
-        if constexpr (MT == 8) {
-          epilogue_sub<EPI, TC, MT, 4, 2>(acc, ep, growW + 64, gcol0, ec, g, lane_e);
-          epilogue_sub<EPI, TC, MT, 6, 2>(acc, ep, growW + 96, gcol0, ec, g, lane_e);
+        epilogue_sub<EPI, TC, MTE, 0, 2>(acc, ep, growW, gcol0, ec, g, lane_e);
+        epilogue_sub<EPI, TC, MTE, 2, 2>(acc, ep, growW + 32, gcol0, ec, g, lane_e);
+        if constexpr (MTE == 8) {
+          epilogue_sub<EPI, TC, MTE, 4, 2>(acc, ep, growW + 64, gcol0, ec, g, lane_e);
+          epilogue_sub<EPI, TC, MTE, 6, 2>(acc, ep, growW + 96, gcol0, ec, g, lane_e);
         }
       }
     } else if (acc[0][0][0] == 123.456f) {
       reinterpret_cast<float*>(g.C)[0] = 1.f;
     }
+    };   // tile_body
+    if constexpr (HALF_OK) {
+      if (hf >= 0) tile_body(std::integral_constant<int, MT / 2>{});   // wave-uniform
+      else tile_body(std::integral_constant<int, MT>{});
+    } else {
+      tile_body(std::integral_constant<int, MT>{});
+    }
     if (j_next < 0) break;
-    j = j_next; tm = tm_next; tn = tn_next; sp = sp_next;
+    j = j_next; tm = tm_next; tn = tn_next; sp = sp_next; hf = hf_next;
     // every wave must be done with its epilogue region before the next K
     // step's DMA overwrites that stage
     __syncthreads();

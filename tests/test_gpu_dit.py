@@ -393,3 +393,38 @@ def test_vocab_gemm_row_lse_from_epilogue(ops, N, mask):
   x = torch.full((rows_out, 1), mask, dtype=torch.int64).cuda()
   lse2 = ops.subs_row_lse(logits[:, None, :N], x, mask)
   assert (lse[kept] - lse2.view(-1)[kept]).abs().max().item() < 1e-5
+
+
+def test_gemm_half_tile_tail_is_bit_identical(ops):
+  """The persistent GEMM cuts the tiles of a short last round into half tiles
+  (same K order per output row).  At 44 samples x 1024 rows the N = 768 GEMMs
+  have 528 tiles on 256 workgroups: two full rounds + 16 tiles run as 32 half
+  tiles.  Results must equal the 128x128 configuration's bit for bit (which never
+  splits), for the gate/residual and the QKV + rotary epilogues, with a device-side
+  row count below the launch bound."""
+  from mdlm_amd._lib import EPI_GATE_RESIDUAL, EPI_QKV_ROTARY
+  torch.manual_seed(11)
+  L, D, H = 1024, 768, 12
+  n_max, n_live = 48, 44
+  M = n_max * L
+  h = _bf(torch.randn(M, D)).cuda()
+  x0 = torch.randn(M, D).cuda()
+  Wo = _bf(torch.randn(D, D) * 0.05).cuda()
+  Wq = _bf(torch.randn(3 * D, D) * 0.05).cuda()
+  mod = torch.randn(1, 6 * D).cuda()
+  cos = torch.randn(L, 32).cuda(); sin = torch.randn(L, 32).cuda()
+  live = torch.tensor([n_live * L], dtype=torch.int32).cuda()
+  res = []
+  for tile in (0, 1):
+    x = x0.clone()
+    ops.gemm_bf16(h, Wo, x, EPI_GATE_RESIDUAL, gate=mod[:, :D], residual=x, rows_per_mod=L,
+                  n_mod=1, mod_ld=6 * D, m_rows_dev=live, tile=tile)
+    qkv = torch.zeros(3 * M * D, dtype=torch.bfloat16).cuda()
+    ops.gemm_bf16(h, Wq, qkv, EPI_QKV_ROTARY, rows_per_mod=L, rot_cos=cos, rot_sin=sin,
+                  n_heads=H, m_rows_dev=live, ldc=0, tile=tile)
+    res.append((x, qkv))
+  assert torch.equal(res[0][0], res[1][0])
+  assert torch.equal(res[0][1], res[1][1])
+  assert torch.equal(res[0][0][n_live * L:], x0[n_live * L:])      # rows past the live count untouched
+  ref = x0[:4096] + mod[:, :D] * (h[:4096].float() @ Wo.float().T)
+  assert _rel(res[0][0][:4096].cpu(), ref.cpu()) < 1e-2
