@@ -181,6 +181,7 @@ def train_bench(args):
                                 f'global batch {world * B}, V={V}, dropout 0.1, clip 1.0, AdamW+EMA',
                     'batch_per_gpu': B, 'parallelism': f'ddp x{world}',
                     'grad_allreduce_mbytes': round(tr.n_flat * 4 / 1e6, 1)},
+         'dist': dist_block(world, dev),
          'loss': round(float(loss), 4),
          'model_tflops': round(3 * f_tok * world * B * L * steps / el / 1e12, 1)}
   if rank == 0:
@@ -223,6 +224,7 @@ def semi_ar_bench(args):
          'config': {'workload': f'semi-AR sample_subs_guidance, DiT-small, window L={L}, stride 512, '
                                 f'num_strides 2 -> {n_tok} tokens, dt=1/{args.T}, batch={B}/GPU',
                     'parallelism': f'replicas x{world}'},
+         'dist': dist_block(world, dev),
          'tokens_per_sec': round(world * B * n_tok * args.steps / el, 1),
          'sec_per_sequence_at_this_batch': round(el / args.steps / B, 4),
          'steps_with_change': int(nfe_steps)}
