@@ -616,3 +616,26 @@ def test_full_size_configs1_backbone_and_fused_step(ops):
   n_un = int((xr != x).sum())
   assert 1 <= n_un <= 40 and int(st['changed'].item()) == 1
   assert torch.equal(xr[x != Mf], x[x != Mf])
+
+
+def test_full_size_trajectory_modes_agree(ops):
+  """BASELINE configs[1] shapes (DiT-small, L = 1024, V = 50,258) over a whole
+  short trajectory: the default path (fast race, per-sample cache, masked-row
+  projection, row lse from the GEMM epilogue) emits the same token ids as the
+  reference race kernel (every element in the defining arithmetic) and as the
+  reference's all-or-nothing cache policy (diffusion.py:682-685) on the same
+  Philox stream."""
+  import bench
+  from mdlm_amd.config import load_config
+  B, T = 2, 48
+  outs = []
+  for ov in ([], ['sampling.fast_math=false'], ['sampling.cache_policy=batch']):
+    cfg = load_config(['model=small', f'loader.eval_batch_size={B}', f'sampling.steps={T}', *ov])
+    model = bench.build_model(cfg, seed=1)
+    model.seed_rng(77)
+    outs.append(model.restore_model_and_sample(num_steps=T).cpu())
+    assert (outs[-1] != model.mask_index).all()
+    del model
+    torch.cuda.empty_cache()
+  assert torch.equal(outs[0], outs[1])
+  assert torch.equal(outs[0], outs[2])
