@@ -305,7 +305,8 @@ def dist_check_bench(args):
 
 # per-kernel roofline bookkeeping of the sampling loop: tag -> (kernel symbol, bound)
 KERNELS = {
-  'gemm_out': ('gemm_bf16_kernel<EPI_GATE_RESIDUAL,fp32> attn_out 768->768', 'mfma'),
+  # 154 flop/byte: below the machine balance (2.5 PF / 8 TB/s = 312), so HBM is its roofline
+  'gemm_out': ('gemm_bf16_kernel<EPI_GATE_RESIDUAL,fp32> attn_out 768->768', 'hbm'),
   'gemm_fc2': ('gemm_bf16_kernel<EPI_GATE_RESIDUAL,fp32> mlp.2 3072->768', 'mfma'),
   'gemm_fc1': ('gemm_bf16_kernel<EPI_BIAS_GELU,bf16> mlp.0 768->3072', 'mfma'),
   'gemm_qkv': ('gemm_bf16_kernel<EPI_QKV_ROTARY,bf16> 768->2304 + rotary', 'mfma'),
@@ -320,6 +321,9 @@ KERNELS = {
   'gemm_gate_residual': ('gemm_bf16_kernel<EPI_GATE_RESIDUAL,fp32,256x256> (attn_out 768->768 and '
                          'mlp.2 3072->768: one symbol in the rocprof trace)', 'mfma'),
 }
+
+
+D_MODEL = 768   # set from the config in main()
 
 
 def kernel_rooflines(events, traffic):
@@ -347,6 +351,10 @@ def kernel_rooflines(events, traffic):
     work = sum(w * r for (_, _, _, w), r in zip(evs, rows))
     t = sum(ms) * 1e-3
     kernel, bound = KERNELS.get(tag, (tag, 'hbm'))
+    if tag == 'gemm_out':
+      # events carry flops per row (2 D^2); as an HBM-bound kernel it is priced on
+      # its bytes: A bf16 (2 D) + residual read and fp32 C write (4 D each) per row
+      work = work / (2.0 * D_MODEL * D_MODEL) * (10.0 * D_MODEL)
     d = {'tag': tag, 'kernel': kernel, 'bound': bound, 'launches': len(ms),
          'avg_launch_ms': round(sum(ms) / n, 4), 'total_ms': round(sum(ms), 2),
          'avg_rows_per_launch': round(sum(rows) / n, 1)}
@@ -425,6 +433,8 @@ def main():
   model.seed_rng(mdist.rank_seed(cfg.seed, rank))
   B, L, V = args.batch, cfg.model.length, model.vocab_size
   D, nb = cfg.model.hidden_size, cfg.model.n_blocks
+  global D_MODEL
+  D_MODEL = D
   bb = model.backbone
 
   def sync_all():

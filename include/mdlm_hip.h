@@ -203,11 +203,14 @@ int mdlm_q_xt(const int64_t* x0, const float* move_chance, const float* u,
 /* (c2) SUBS + gather + NELBO weight, diffusion.py:884-894 and 908:
  *   nll[b,l] = -log p_theta(x0[b,l] | xt) * weight[b] * attn_mask[b,l]
  * with weight = dsigma/expm1(sigma) supplied per sample; log-probs are never
- * materialised.  attn_mask may be NULL (= ones). */
+ * materialised.  attn_mask may be NULL (= ones).  row_lse (B*L, optional): the
+ * SUBS row lse of the masked rows if the caller already has it (mdlm_lse_combine
+ * after the vocabulary GEMM) -- the kernel then reads one logit per row instead
+ * of the row. */
 int mdlm_subs_nll(const void* logits, int64_t ld, int dtype, const int64_t* xt,
                   const int64_t* x0, const float* weight,
-                  const float* attn_mask, float* nll, int B, int L, int V,
-                  int mask_index, void* stream);
+                  const float* attn_mask, const float* row_lse, float* nll,
+                  int B, int L, int V, int mask_index, void* stream);
 
 /* fp64 metric sums, diffusion.py:44-65,369-376 (MeanMetric in float64):
  * sums[0] += sum(nll), sums[1] += sum(attn_mask) (or n if NULL).  One

@@ -37,7 +37,7 @@ SIGNATURES = {
   'mdlm_gather_rows': [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp],
   'mdlm_philox_uniform': [_vp, _i64, _i32, _u64, _u64, _vp],
   'mdlm_q_xt': [_vp, _vp, _vp, _u64, _u64, _vp, _i32, _i32, _i32, _vp],
-  'mdlm_subs_nll': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
+  'mdlm_subs_nll': [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                     _i32, _vp],
   'mdlm_nll_sums': [_vp, _vp, _vp, _i64, _vp],
   'mdlm_embed_rows': [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _vp],

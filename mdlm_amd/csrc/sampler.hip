@@ -1234,11 +1234,35 @@ extern "C" int mdlm_q_xt(const int64_t* x0, const float* move_chance,
   return 0;
 }
 
+namespace mdlm {
+// the same with the row lse already known (from the vocabulary GEMM's epilogue,
+// mdlm_lse_combine): one gathered logit per row, one thread per row
+template <typename T>
+__global__ __launch_bounds__(256) void subs_nll_lse_kernel(
+    const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ xt,
+    const int64_t* __restrict__ x0, const float* __restrict__ weight,
+    const float* __restrict__ attn_mask, const float* __restrict__ row_lse,
+    float* __restrict__ nll, int64_t rows, int L, int mask) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const int64_t tok = xt[r], tgt = x0[r];
+  float logp;
+  if (tok != mask) {
+    logp = (tgt == tok) ? 0.f : NEG_INF;
+  } else {
+    float x = elem<T>::load(logits + r * ld + tgt);
+    if (tgt == mask) x += NEG_INF;
+    logp = x - row_lse[r];
+  }
+  nll[r] = (-logp * weight[r / L]) * (attn_mask ? attn_mask[r] : 1.f);
+}
+}  // namespace mdlm
+
 extern "C" int mdlm_subs_nll(const void* logits, int64_t ld, int dtype,
                              const int64_t* xt, const int64_t* x0,
                              const float* weight, const float* attn_mask,
-                             float* nll, int B, int L, int V, int mask_index,
-                             void* stream) {
+                             const float* row_lse, float* nll, int B, int L, int V,
+                             int mask_index, void* stream) {
   if (B == 0) return 0;
   MDLM_CHECK_ARG(logits && xt && x0 && weight && nll, "subs_nll: null pointer");
   MDLM_CHECK_ARG(B >= 0 && L > 0 && V > 0 && ld >= V && (int64_t)B * L < (1ll << 31), "subs_nll: bad shape");
@@ -1246,6 +1270,13 @@ extern "C" int mdlm_subs_nll(const void* logits, int64_t ld, int dtype,
   MDLM_CHECK_ARG(dtype == MDLM_F32 || dtype == MDLM_BF16, "subs_nll: bad dtype");
   if (B == 0) return 0;
   const unsigned rows = (unsigned)((int64_t)B * L);
+  if (row_lse) {
+    const unsigned nb = (rows + 255) / 256;
+    if (dtype == MDLM_F32) subs_nll_lse_kernel<float><<<nb, 256, 0, ST(stream)>>>((const float*)logits, ld, xt, x0, weight, attn_mask, row_lse, nll, rows, L, mask_index);
+    else subs_nll_lse_kernel<bf16_t><<<nb, 256, 0, ST(stream)>>>((const bf16_t*)logits, ld, xt, x0, weight, attn_mask, row_lse, nll, rows, L, mask_index);
+    MDLM_LAUNCH_CHECK();
+    return 0;
+  }
   if (dtype == MDLM_F32) subs_nll_kernel<float><<<rows, NT, 0, ST(stream)>>>((const float*)logits, ld, xt, x0, weight, attn_mask, nll, L, V, mask_index);
   else subs_nll_kernel<bf16_t><<<rows, NT, 0, ST(stream)>>>((const bf16_t*)logits, ld, xt, x0, weight, attn_mask, nll, L, V, mask_index);
   MDLM_LAUNCH_CHECK();

@@ -204,7 +204,7 @@ class Diffusion(_Base):
     assert sigma.ndim == 1, sigma.shape
     return sigma
 
-  def _backbone_logits(self, x, sigma, masked_rows_only=False):
+  def _backbone_logits(self, x, sigma, masked_rows_only=False, want_lse=False):
     """Backbone logits (B, L, V) bf16.  masked_rows_only: the caller reads
     logits of masked positions only (NELBO: unmasked rows contribute exactly 0,
     diffusion.py:270-277), so the final LayerNorm + vocabulary projection run
@@ -224,14 +224,21 @@ class Diffusion(_Base):
                   n=torch.full((1,), B, **i32),
                   gather=torch.zeros(n_map, **i32),
                   scatter=torch.zeros(n_map, **i32),
-                  n_mrows=torch.zeros(1, **i32))
+                  n_mrows=torch.zeros(1, **i32),
+                  lse=torch.zeros(B * Lq, dtype=torch.float32, device=x.device))
         self._eval_state = es
       ops.masked_row_map(x, es['ident'], es['n'], Lq, self.mask_index,
                          es['gather'], es['scatter'], es['n_mrows'])
       row_map = (es['gather'], es['scatter'], es['n_mrows'])
-    return self.backbone.run(x, sigma, out,
-                             sigma_is_zero=not self.time_conditioning,
-                             row_map=row_map)
+    lse = None
+    if (want_lse and row_map is not None
+        and self.config.sampling.get('lse_from_gemm', True)):
+      lse = self._eval_state['lse']   # SUBS row lse out of the vocabulary GEMM's epilogue
+    logits = self.backbone.run(x, sigma, out,
+                               sigma_is_zero=not self.time_conditioning,
+                               row_map=row_map, lse_out=lse,
+                               lse_skip_col=self.mask_index)
+    return (logits, lse) if want_lse else logits
 
   def forward(self, x, sigma):
     """Returns log score (diffusion.py:312-327): SUBS log-probs (B, L, V)."""
@@ -657,15 +664,16 @@ class Diffusion(_Base):
     sigma, dsigma = self.noise(t)
     move_chance = 1 - torch.exp(-sigma[:, None])
     xt = self.q_xt(x0, move_chance, u=u)
-    logits = self._backbone_logits(xt, sigma[:, None], masked_rows_only=True)
+    logits, lse = self._backbone_logits(xt, sigma[:, None], masked_rows_only=True,
+                                        want_lse=True)
     if self.T > 0:
       neg_logp = ops.subs_nll(logits, xt, x0, torch.ones_like(sigma),
-                              self.mask_index)
+                              self.mask_index, row_lse=lse)
       return ops.d3pm_loss(neg_logp, xt, t, self.T, self.mask_index,
                            attn_mask=attention_mask)
     weight = dsigma / torch.expm1(sigma)
     return ops.subs_nll(logits, xt, x0, weight, self.mask_index,
-                        attn_mask=attention_mask)
+                        attn_mask=attention_mask, row_lse=lse)
 
   def _loss(self, x0, attention_mask, *, t=None, u=None):
     """diffusion.py:896-916 -> Loss(loss=token_nll, nlls, token_mask)."""

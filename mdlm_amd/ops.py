@@ -267,7 +267,7 @@ def q_xt(x0, move_chance, mask_index, u=None, seed=0, offset=0):
   return xt
 
 
-def subs_nll(logits, xt, x0, weight, mask_index, attn_mask=None):
+def subs_nll(logits, xt, x0, weight, mask_index, attn_mask=None, row_lse=None):
   lg, rows, V, ld = _rows2d(logits, 'logits')
   xt = _dev(xt, 'xt', torch.int64).contiguous()
   x0 = _dev(x0, 'x0', torch.int64).contiguous()
@@ -279,7 +279,7 @@ def subs_nll(logits, xt, x0, weight, mask_index, attn_mask=None):
     attn_mask = _dev(attn_mask, 'attn_mask').to(torch.float32).contiguous()
   nll = torch.empty(B, L, dtype=torch.float32, device=logits.device)
   call('mdlm_subs_nll', lg.data_ptr(), ld, _DT[lg.dtype], xt.data_ptr(),
-       x0.data_ptr(), w.data_ptr(), _p(attn_mask), nll.data_ptr(), B, L, V,
+       x0.data_ptr(), w.data_ptr(), _p(attn_mask), _p(row_lse), nll.data_ptr(), B, L, V,
        int(mask_index), _stream())
   return nll
 
