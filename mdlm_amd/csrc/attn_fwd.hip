@@ -350,22 +350,16 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_pipe_kernel(
     }
   };
   const int pr = (r & ~0xC) | ((r & 4) << 1) | ((r & 8) >> 1);
-  int koff[2][4];
+  // LDS byte offsets of this lane's fragments inside a stage: the swizzle term
+  // (row >> 1) & 7 does not change with +32 rows, so the second key half / second
+  // d block is the same offset + 4096 (an instruction immediate)
+  int koff[4], voff[4];
 #pragma unroll
-  for (int kt2 = 0; kt2 < 2; ++kt2) {
-    const int row = kt2 * 32 + pr;
+  for (int ks = 0; ks < 4; ++ks)
+    koff[ks] = pr * 128 + (((ks * 2 + hh) ^ ((pr >> 1) & 7)) * 16);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      koff[kt2][ks] = row * 128 + (((ks * 2 + hh) ^ ((row >> 1) & 7)) * 16);
-  }
-  int voff[2][4];
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt) {
-    const int row = dt * 32 + r;
-#pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4)
-      voff[dt][c4] = KV_TILE + row * 128 + ((((c4 >> 1) * 4 + (c4 & 1) * 2 + hh) ^ ((row >> 1) & 7)) * 16);
-  }
+  for (int c4 = 0; c4 < 4; ++c4)
+    voff[c4] = KV_TILE + r * 128 + ((((c4 >> 1) * 4 + (c4 & 1) * 2 + hh) ^ ((r >> 1) & 7)) * 16);
 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 oacc[2][2] = {{zero16, zero16}, {zero16, zero16}};
@@ -378,7 +372,7 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_pipe_kernel(
   auto load_k = [&](int kt2, int st) {
     const char* base = smem + st * (2 * KV_TILE);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kf[kt2][ks] = *reinterpret_cast<const bf16x8*>(base + koff[kt2][ks]);
+    for (int ks = 0; ks < 4; ++ks) kf[kt2][ks] = *reinterpret_cast<const bf16x8*>(base + koff[ks] + kt2 * 4096);
   };
   auto load_v = [&](int kt2, int st) {
     const char* base = smem + st * (2 * KV_TILE);
@@ -386,7 +380,7 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_pipe_kernel(
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
-        vf[dt][kt2 * 2 + s2] = *reinterpret_cast<const bf16x8*>(base + voff[dt][kt2 * 2 + s2]);
+        vf[dt][kt2 * 2 + s2] = *reinterpret_cast<const bf16x8*>(base + voff[kt2 * 2 + s2] + dt * 4096);
   };
 
   const int NT = L / KB;
@@ -409,18 +403,20 @@ __global__ __launch_bounds__(AT, 2) void attn_fwd_pipe_kernel(
   auto step = [&](auto t_c, auto nk_c, auto pk_c) {
     constexpr int T = decltype(t_c)::value, NK = decltype(nk_c)::value, PK = decltype(pk_c)::value;
     constexpr int O = 1 - T;
-    // ---- region A: first half of the next QK^T beside the block max --------
+    // MFMA order: the links of the S[O] chain (each waits for its predecessor's
+    // result) alternate with the four independent P.V products of the previous block
+    auto pv = [&](int i) {
+      const int s2 = i >> 1, dt = i & 1;
+      oacc[O][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][PK * 2 + s2], P[O][s2], oacc[O][dt], 0, 0, 0);
+    };
     S[O] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[NK][0], qf[O][0], zero16, 0, 0, 0);
+    pv(0);
     S[O] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[NK][1], qf[O][1], S[O], 0, 0, 0);
-    // ---- region B: rest of QK^T, the previous block's PV, beside exp / sum / pack
+    pv(1);
     S[O] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[NK][2], qf[O][2], S[O], 0, 0, 0);
+    pv(2);
     S[O] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[NK][3], qf[O][3], S[O], 0, 0, 0);
-    // the two accumulators alternate: no MFMA waits for its predecessor
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-        oacc[O][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][PK * 2 + s2], P[O][s2], oacc[O][dt], 0, 0, 0);
+    pv(3);
     auto softmax_block = [&](bool with_max) -> float {
       if (with_max) {
         asm volatile("" : "+v"(S[T][0]));   // keep the max ops inside the rare path
