@@ -455,6 +455,7 @@ def main():
   elapsed = mdist.max_over_ranks(elapsed, dev)
   nfe_last = int(model.last_nfe.item())
   n_exact = int(model.last_n_exact.item())
+  n_groups = len((model._state or {}).get('groups') or [None])
 
   # ---- profiling batch (outside the timed region): HIP events on the launch
   # stream around every kernel of each k-th step, live row counts of every step
@@ -498,6 +499,7 @@ def main():
                         'bit-exact; every element in the defining arithmetic '
                         '(sampling.fast_math=false)'),
                'rng': 'in-kernel Philox4x32-7',
+               'stream_groups': n_groups,
                'parallelism': f'replicas x{world}',
                **({'overrides': args.set} if args.set else {})},
     'dist': dist_info,
@@ -516,7 +518,10 @@ def main():
                               key=lambda d: -d['total_ms'])
     out['profile'] = {'stride': args.profile_stride,
                       'note': ('separate batch after the timed region; HIP events on the launch '
-                               'stream around every kernel launch of each k-th denoising step')}
+                               'stream around every kernel launch of each k-th denoising step; '
+                               'the whole batch on ONE stream so that every kernel is timed alone '
+                               '(the timed region overlaps the forwards of config.stream_groups '
+                               'sample ranges on as many streams)')}
   # model flops charge every sample-forward 291.65 GFLOP; executed
   # flops count the vocabulary projection and the last block's tail on masked rows only
   out['model_tflops'] = round((nfe_last * 291.65e9 * args.steps) / elapsed / 1e12, 1)

@@ -71,8 +71,11 @@ DEFAULTS = dict(
                 # in the defining arithmetic, false evaluates every element in it
                 # (include/mdlm_hip.h).  lazy_unmask is NOT result-identical
                 # (same law, different map from random numbers): opt-in.
+                # stream_groups: the batch is cut into that many sample ranges whose
+                # backbone forwards run on separate HIP streams (result-identical).
                 fused=True, cache_policy='sample', fast_math=True,
                 masked_rows_only=True, lse_from_gemm=True, lazy_unmask=False,
+                stream_groups=2,
                 p_x0_dtype='bf16'),
   training=dict(ema=0.9999, antithetic_sampling=True,
                 importance_sampling=False, sampling_eps=1e-3,

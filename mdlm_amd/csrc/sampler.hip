@@ -885,7 +885,8 @@ __global__ void compact_active_kernel(const int32_t* __restrict__ changed,
   }
   if (threadIdx.x == 0) {
     *n_active = base; *n_rows = base * L;
-    if (nfe_accum) *nfe_accum += base;
+    // atomic: the stream groups of one sampling step compact concurrently
+    if (nfe_accum) atomicAdd(reinterpret_cast<unsigned long long*>(nfe_accum), (unsigned long long)base);
   }
 }
 

@@ -375,6 +375,72 @@ class Diffusion(_Base):
     self._state = st
     return st
 
+  def _stream_groups(self, st, aon):
+    """Sample ranges whose backbone forwards run concurrently (sampling.stream_groups,
+    per-sample cache policy only).  Every group has its own active list, row lists
+    and DiT workspace; group 0 runs on the caller's stream."""
+    B, Lq = st['B'], st['L']
+    G = int(self.config.sampling.get('stream_groups', 1))
+    if (aon or G < 2 or B % G or ((B // G) * Lq) % 256 or self._profile is not None
+        or bool(self.config.sampling.get('lazy_unmask', False))):
+      G = 1
+    if st.get('groups') is not None and len(st['groups']) == G:
+      return st['groups']
+    dev = st['dev']
+    i32 = dict(dtype=torch.int32, device=dev)
+    nb = B // G
+    groups = []
+    for g in range(G):
+      if G == 1:
+        grp = dict(g=0, s0=0, nb=B, active=st['active'], n_active=st['n_active'], n_rows=st['n_rows'],
+                   gather=st['gather'], scatter=st['scatter'], n_mrows=st['n_mrows'])
+      else:
+        n_map = ops.workspace_bytes('masked_row_map', nb * Lq, 256) // 4
+        grp = dict(g=g, s0=g * nb, nb=nb, active=torch.zeros(nb, **i32),
+                   n_active=torch.zeros(1, **i32), n_rows=torch.zeros(1, **i32),
+                   gather=torch.zeros(n_map, **i32), scatter=torch.zeros(n_map, **i32),
+                   n_mrows=torch.zeros(1, **i32),
+                   stream=torch.cuda.Stream(device=dev) if g else None,
+                   ev=torch.cuda.Event() if g else None)
+      groups.append(grp)
+    if G > 1:
+      st['ev_fork'] = torch.cuda.Event()
+    st['groups'] = groups
+    return groups
+
+  def _refresh_group(self, st, grp, x, aon, want_lse):
+    """`_refresh_cache` for the samples [s0, s0 + nb) on the current stream."""
+    Lq = st['L']
+    s0, nb = grp['s0'], grp['nb']
+    r0, r1 = s0 * Lq, (s0 + nb) * Lq
+    xg = x[s0:s0 + nb]
+    timed = self.backbone._timed
+    timed('row_lists', 0, 0.0, lambda: ops.compact_active(
+      st['changed'][s0:s0 + nb], grp['active'], grp['n_active'], grp['n_rows'], Lq,
+      all_or_nothing=aon, nfe_accum=st['nfe'], fresh=st['fresh'][s0:s0 + nb]))
+    row_map = None
+    if self.config.sampling.get('masked_rows_only', True) and (st['B'] * Lq) % 256 == 0:
+      # only masked rows need logits: carry-over / SUBS ignore the others
+      timed('row_lists', 0, 0.0, lambda: ops.masked_row_map(
+        xg, grp['active'], grp['n_active'], Lq, self.mask_index, grp['gather'],
+        grp['scatter'], grp['n_mrows']))
+      row_map = (grp['gather'], grp['scatter'], grp['n_mrows'])
+    if self._profile is not None:
+      self._profile['rows'].append((grp['n_rows'].clone(), grp['n_mrows'].clone()
+                                    if row_map is not None else grp['n_rows'].clone()))
+    # row lse of the refreshed rows: out of the vocabulary GEMM's epilogue
+    # when only the masked rows are projected (SURVEY 8(f)-1), else inside the
+    # update kernel (`fresh` flags); a separate pass only when asked for
+    lse_gemm = row_map is not None and self.config.sampling.get('lse_from_gemm', True)
+    self.backbone.run(xg, st['zeros'][s0:s0 + nb], st['cache'][s0:s0 + nb], sigma_is_zero=True,
+                      active=grp['active'], n_active_dev=grp['n_active'],
+                      n_rows_dev=grp['n_rows'], n_max=nb, row_map=row_map,
+                      lse_out=st['lse'][r0:r1] if lse_gemm else None,
+                      lse_skip_col=self.mask_index, ws_key=grp['g'])
+    if want_lse and not lse_gemm:
+      ops.subs_row_lse(st['cache'][s0:s0 + nb], xg, self.mask_index, out=st['lse'][r0:r1],
+                       sample_map=grp['active'], L=Lq, n_rows_dev=grp['n_rows'])
+
   def _refresh_cache(self, st, x, sigma=None, want_lse=False):
     """Evaluate the backbone for the samples whose tokens changed since their
     cached logits were computed (device-side replacement of the host decision
@@ -384,33 +450,28 @@ class Diffusion(_Base):
                   self.config.sampling.get('cache_policy', 'sample') != 'none')
     if per_sample:
       aon = self.config.sampling.get('cache_policy', 'sample') == 'batch'
-      timed = self.backbone._timed
-      timed('row_lists', 0, 0.0, lambda: ops.compact_active(
-        st['changed'], st['active'], st['n_active'], st['n_rows'], Lq,
-        all_or_nothing=aon, nfe_accum=st['nfe'], fresh=st['fresh']))
-      row_map = None
-      if self.config.sampling.get('masked_rows_only', True) and (B * Lq) % 256 == 0:
-        # only masked rows need logits: carry-over / SUBS ignore the others
-        timed('row_lists', 0, 0.0, lambda: ops.masked_row_map(
-          x, st['active'], st['n_active'], Lq, self.mask_index, st['gather'],
-          st['scatter'], st['n_mrows']))
-        row_map = (st['gather'], st['scatter'], st['n_mrows'])
-      if self._profile is not None:
-        self._profile['rows'].append((st['n_rows'].clone(), st['n_mrows'].clone()
-                                      if row_map is not None else st['n_rows'].clone()))
-      # row lse of the refreshed rows: out of the vocabulary GEMM's epilogue
-      # when only the masked rows are projected, else inside the
-      # update kernel (`fresh` flags); a separate pass only when asked for
-      lse_gemm = row_map is not None and self.config.sampling.get('lse_from_gemm', True)
-      self.backbone.run(x, st['zeros'], st['cache'], sigma_is_zero=True,
-                        active=st['active'], n_active_dev=st['n_active'],
-                        n_rows_dev=st['n_rows'], n_max=B, row_map=row_map,
-                        lse_out=st['lse'] if lse_gemm else None,
-                        lse_skip_col=self.mask_index)
+      groups = self._stream_groups(st, aon)
+      lse_gemm = (self.config.sampling.get('masked_rows_only', True) and (B * Lq) % 256 == 0
+                  and self.config.sampling.get('lse_from_gemm', True))
+      if len(groups) == 1:
+        self._refresh_group(st, groups[0], x, aon, want_lse)
+      else:
+        # the halves of the batch are independent until the update kernel: their
+        # forwards run on two streams, so that one's partial last GEMM round and
+        # HBM-bound kernels overlap the other's MFMA work
+        cur = torch.cuda.current_stream()
+        bb = self.backbone   # lazily built operands shared by the groups: before the fork
+        bb.conditioning(bb._prepare(Lq), None, True)
+        st['ev_fork'].record(cur)
+        for grp in groups[1:]:
+          grp['stream'].wait_event(st['ev_fork'])
+          with torch.cuda.stream(grp['stream']):
+            self._refresh_group(st, grp, x, aon, want_lse)
+            grp['ev'].record(grp['stream'])
+        self._refresh_group(st, groups[0], x, aon, want_lse)
+        for grp in groups[1:]:
+          cur.wait_event(grp['ev'])
       st['lse_ready'] = lse_gemm
-      if want_lse and not lse_gemm:
-        ops.subs_row_lse(st['cache'], x, self.mask_index, out=st['lse'],
-                         sample_map=st['active'], L=Lq, n_rows_dev=st['n_rows'])
     else:
       # time conditioning: sigma changes every step, no caching at all
       st['nfe'] += B

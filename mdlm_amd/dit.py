@@ -114,6 +114,7 @@ class DIT(nn.Module):
     self.profile_events = None   # bench.py profiling pass only (see _timed)
     self.profile_sample = False
     self._ws = None     # activation workspace
+    self._ws_groups = {}
 
   # ------------------------------------------------------------ preparation
   def refresh(self):
@@ -129,6 +130,7 @@ class DIT(nn.Module):
     r = super()._apply(fn, *a, **k)
     self._prep = None
     self._ws = None
+    self._ws_groups = {}
     return r
 
   def _prepare(self, L):
@@ -173,7 +175,15 @@ class DIT(nn.Module):
     self._prep = p
     return p
 
-  def _workspace(self, M):
+  def _workspace(self, M, key=0):
+    """Activation workspace; `key` names an independent copy (one per stream
+    group of the sampling loop, whose forwards run concurrently)."""
+    if key:
+      if self._ws_groups.get(key) is None or self._ws_groups[key]['M'] < M:
+        keep, self._ws = self._ws, None
+        self._ws_groups[key] = self._workspace(M)
+        self._ws = keep
+      return self._ws_groups[key]
     if self._ws is not None and self._ws['M'] >= M:
       return self._ws
     dev = self.vocab_embed.embedding.device
@@ -233,7 +243,7 @@ class DIT(nn.Module):
 
   def run(self, indices, sigma, logits_out, sigma_is_zero=False, active=None,
           n_active_dev=None, n_rows_dev=None, n_max=None, row_map=None,
-          hidden_out=None, lse_out=None, lse_skip_col=-1):
+          hidden_out=None, lse_out=None, lse_skip_col=-1, ws_key=0):
     """Run the backbone.  `indices` (B, L) int64.  `logits_out`: (B, L, V)
     bf16/fp32 view (padded leading dimension allowed).  If `active` (int32
     device list) is given, only the listed samples are evaluated (compacted
@@ -254,7 +264,7 @@ class DIT(nn.Module):
     D, H = self.hidden, self.n_heads
     n_seq = B if n_max is None else n_max
     M = n_seq * L
-    ws = self._workspace(M)
+    ws = self._workspace(M, ws_key)
     x, h, qkv, ao, mh = ws['x'][:M], ws['h'][:M], ws['qkv'], ws['ao'][:M], ws['mh'][:M]
     mods, n_mod = self.conditioning(p, sigma, sigma_is_zero)
     if n_mod != 1 and active is not None:

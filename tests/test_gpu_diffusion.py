@@ -175,6 +175,32 @@ def test_fast_and_reference_race_emit_the_same_tokens(ops):
   assert 0.5 * 32 < outs[0][1] / 8 <= 33
 
 
+def test_stream_groups_are_result_identical(ops):
+  """`sampling.stream_groups` runs the backbone forwards of disjoint sample
+  ranges on separate HIP streams (per-group active lists, row lists and
+  workspaces, joined before the update kernel): same tokens, same NFE, also in
+  the semi-AR driver that shares the cache refresh."""
+  outs = []
+  for g in (1, 2, 4):
+    model, cfg, _ = make_model([f'sampling.stream_groups={g}', 'loader.eval_batch_size=8'])
+    model.seed_rng(11)
+    x = model._sample(num_steps=40).cpu()
+    nfe = int(model.last_nfe.item())
+    assert len(model._state['groups']) == g
+    model.seed_rng(12)
+    _, inter, _ = model.sample_subs_guidance(n_samples=8, stride_length=64, num_strides=1, dt=1 / 16)
+    outs.append((x, nfe, inter))
+  for o in outs[1:]:
+    assert torch.equal(outs[0][0], o[0]) and outs[0][1] == o[1]
+    assert outs[0][2] == o[2]
+  assert (outs[0][0] != MASK).all()
+  # a batch that does not split into 256-row multiples falls back to one group
+  model, cfg, _ = make_model(['sampling.stream_groups=2', 'loader.eval_batch_size=3'])
+  model.seed_rng(11)
+  model._sample(num_steps=8)
+  assert len(model._state['groups']) == 1
+
+
 def test_time_conditioning_path(ops):
   model, cfg, p = make_model(['time_conditioning=true'])
   model.seed_rng(9)
@@ -629,7 +655,8 @@ def test_full_size_trajectory_modes_agree(ops):
   from mdlm_amd.config import load_config
   B, T = 2, 48
   outs = []
-  for ov in ([], ['sampling.fast_math=false'], ['sampling.cache_policy=batch']):
+  for ov in ([], ['sampling.fast_math=false'], ['sampling.cache_policy=batch'],
+             ['sampling.stream_groups=2']):
     cfg = load_config(['model=small', f'loader.eval_batch_size={B}', f'sampling.steps={T}', *ov])
     model = bench.build_model(cfg, seed=1)
     model.seed_rng(77)
@@ -639,3 +666,4 @@ def test_full_size_trajectory_modes_agree(ops):
     torch.cuda.empty_cache()
   assert torch.equal(outs[0], outs[1])
   assert torch.equal(outs[0], outs[2])
+  assert torch.equal(outs[0], outs[3])
