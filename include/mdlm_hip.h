@@ -284,7 +284,10 @@ int mdlm_ln_modulate(const float* x, const float* ln_w, const float* shift,
  * GEMM's own (compact) row.  mdlm_lse_combine turns them into the row lse.
  * tile: 0 = choose (256x256 when M % 256 == 0 and N >= 256, else 128x128),
  * 1 = 128x128 always -- per call, so both configurations can be parity-tested on
- * any shape; the library holds no tuning state. */
+ * any shape; the library holds no tuning state.  | 16: keep whole tiles in a short
+ * last round (default: such tiles are cut into two half tiles of 128 rows, which
+ * finishes a lone launch sooner but costs more CU time -- callers that overlap
+ * launches on several streams pass 16).  Results do not depend on either. */
 int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
                    void* C, int64_t ldc, int dtype_c, int64_t M, int N, int K,
                    int epilogue, const float* gate, const float* residual,

@@ -60,6 +60,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int vec_ok;  // ldc / alignment allow 16-byte row stores
   int dbg;     // MDLM_GEMM_ABLATION builds only (2: skip the epilogue, 4: drop the stores)
+  int whole_tiles;   // tile bit 4: never cut the tiles of a short last round in two
 };
 
 // Timing ablations exist only in builds with -DMDLM_GEMM_ABLATION (scratch/
@@ -534,12 +535,15 @@ void gemm_bf16_kernel(GemmArgs g) {
   // Only where it pays (same-process sweep over 30-54 active samples, scratch/sweep_half.py):
   // gate/residual -4.5 % / -2.6 % (K = 768 / 3072), QKV -1.9 %; the GELU and plain-store
   // instantiations sit at the 256-register limit and the second tile body spills them (+5 %).
-  constexpr bool HALF_OK = !SPLITK && MT == 8 &&
+#ifndef MDLM_GEMM_HALF
+#define MDLM_GEMM_HALF 1
+#endif
+  constexpr bool HALF_OK = MDLM_GEMM_HALF && !SPLITK && MT == 8 &&
                            (EPI == MDLM_EPI_GATE_RESIDUAL || EPI == MDLM_EPI_QKV_ROTARY);
   const int cnt = s_end > s_begin ? s_end - s_begin : 0;
   const int full_r = cnt / slots;
   const int rx = cnt - full_r * slots;
-  const bool split_tail = HALF_OK && rx > 0 && 2 * rx <= slots;
+  const bool split_tail = HALF_OK && !g.whole_tiles && rx > 0 && 2 * rx <= slots;
   const int n_full = split_tail ? full_r * slots : cnt;   // virtual indices below: whole tiles
   const int n_virt = split_tail ? n_full + 2 * rx : cnt;
   // tile at virtual index j of this XCD's range (-1: past its end); hf = -1 for a
@@ -837,7 +841,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
                               int lse_skip_col, int tile, void* stream) {
   if (M == 0) return 0;
   MDLM_CHECK_ARG(A && W && C, "gemm_bf16: null pointer");
-  MDLM_CHECK_ARG((tile & ~15) == 0, "gemm_bf16: tile must be 0 (auto) or 1 (128x128)");
+  MDLM_CHECK_ARG((tile & ~31) == 0, "gemm_bf16: tile must be 0 (auto), 1 (128x128), optionally | 16 (whole tiles only)");
   MDLM_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_bf16: bad shape");
   MDLM_CHECK_ARG(M % 128 == 0, "gemm_bf16: M=%lld must be a multiple of 128", (long long)M);
   MDLM_CHECK_ARG(K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d", K, BK);
@@ -853,6 +857,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
   g.mod_ld = mod_ld; g.out_sample_map = out_sample_map; g.out_row_map = out_row_map;
   g.rot_cos = rot_cos; g.rot_sin = rot_sin; g.n_heads = n_heads; g.m_rows_dev = m_rows_dev;
   g.tiles_m = 0; g.tiles_n = 0; g.dbg = tile & 14;   // ablation builds only
+  g.whole_tiles = (tile >> 4) & 1;
   tile &= 1;
   g.ldw = K; g.splits = 1; g.c_split_stride = 0; g.aux = nullptr;
   g.lse_part = reinterpret_cast<float2*>(lse_partials_out); g.lse_skip = lse_skip_col;
@@ -934,7 +939,7 @@ extern "C" int mdlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
   g.C = partials; g.ldc = N; g.M = M; g.N = N; g.K = (int)(K_total / splits);
   g.gate = nullptr; g.residual = nullptr; g.rows_per_mod = 1; g.n_mod = 1; g.mod_ld = 0;
   g.out_sample_map = nullptr; g.out_row_map = nullptr; g.rot_cos = nullptr; g.rot_sin = nullptr;
-  g.n_heads = 0; g.m_rows_dev = nullptr; g.tiles_m = 0; g.tiles_n = 0; g.dbg = 0;
+  g.n_heads = 0; g.m_rows_dev = nullptr; g.tiles_m = 0; g.tiles_n = 0; g.dbg = 0; g.whole_tiles = 0;
   g.splits = splits; g.c_split_stride = M * (int64_t)N; g.vec_ok = 1; g.aux = nullptr;
   g.lse_part = nullptr; g.lse_skip = -1; g.lse_ng = 0;
   return launch_gemm<MDLM_EPI_STORE, float>(g, (hipStream_t)stream);
@@ -973,7 +978,7 @@ extern "C" int mdlm_gemm_bf16_gelu(const void* A, int64_t lda, const void* W, co
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.gate = nullptr; g.residual = nullptr;
   g.rows_per_mod = 1; g.n_mod = 1; g.mod_ld = 0; g.out_sample_map = nullptr; g.out_row_map = nullptr;
   g.rot_cos = nullptr; g.rot_sin = nullptr; g.n_heads = 0; g.m_rows_dev = nullptr;
-  g.tiles_m = 0; g.tiles_n = 0; g.dbg = 0; g.splits = 1; g.c_split_stride = 0; g.vec_ok = 1;
+  g.tiles_m = 0; g.tiles_n = 0; g.dbg = 0; g.whole_tiles = 0; g.splits = 1; g.c_split_stride = 0; g.vec_ok = 1;
   g.aux = aux;
   g.lse_part = nullptr; g.lse_skip = -1; g.lse_ng = 0;
   if (mode == 0) return launch_gemm<EPI_BIAS_GELU_SAVE, bf16_t>(g, (hipStream_t)stream);

@@ -436,7 +436,8 @@ class Diffusion(_Base):
                       active=grp['active'], n_active_dev=grp['n_active'],
                       n_rows_dev=grp['n_rows'], n_max=nb, row_map=row_map,
                       lse_out=st['lse'][r0:r1] if lse_gemm else None,
-                      lse_skip_col=self.mask_index, ws_key=grp['g'])
+                      lse_skip_col=self.mask_index, ws_key=grp['g'],
+                      concurrent=len(st['groups']) > 1)
     if want_lse and not lse_gemm:
       ops.subs_row_lse(st['cache'][s0:s0 + nb], xg, self.mask_index, out=st['lse'][r0:r1],
                        sample_map=grp['active'], L=Lq, n_rows_dev=grp['n_rows'])

@@ -243,7 +243,8 @@ class DIT(nn.Module):
 
   def run(self, indices, sigma, logits_out, sigma_is_zero=False, active=None,
           n_active_dev=None, n_rows_dev=None, n_max=None, row_map=None,
-          hidden_out=None, lse_out=None, lse_skip_col=-1, ws_key=0):
+          hidden_out=None, lse_out=None, lse_skip_col=-1, ws_key=0,
+          concurrent=False):
     """Run the backbone.  `indices` (B, L) int64.  `logits_out`: (B, L, V)
     bf16/fp32 view (padded leading dimension allowed).  If `active` (int32
     device list) is given, only the listed samples are evaluated (compacted
@@ -258,7 +259,10 @@ class DIT(nn.Module):
     later for the rows that need it).  `lse_out` (B*L) fp32 with a row map:
     the SUBS row lse (column `lse_skip_col` = the mask token excluded) of the
     projected rows comes out of the vocabulary GEMM's epilogue and is written to
-    lse_out[scatter[row]] -- no pass over the logits."""
+    lse_out[scatter[row]] -- no pass over the logits.  `ws_key`: which workspace
+    copy to use; `concurrent`: another forward runs on another stream at the same
+    time (the GEMMs then keep whole tiles in a short last round: a half tile
+    finishes sooner but costs 1.5x the CU time, which the other stream could use)."""
     B, L = indices.shape
     p = self._prepare(L)
     D, H = self.hidden, self.n_heads
@@ -299,6 +303,7 @@ class DIT(nn.Module):
         ws['lsep_key'] = (M, V)
       lsep = ws['lsep']
     n_blocks = len(p['blocks'])
+    gt = (ops.DEFAULT_GEMM_TILE | 16) if concurrent else None
     for bi, (bp, mod) in enumerate(zip(p['blocks'], mods)):
       # chunk order dit.py:249-250: shift_msa, scale_msa, gate_msa, shift_mlp,
       # scale_mlp, gate_mlp
@@ -306,7 +311,7 @@ class DIT(nn.Module):
         x, bp['n1'], mod[:, 0:D], mod[:, D:2 * D], h, L, n_mod, ld6, n_rows_dev))
       T('gemm_qkv', rows_t, GEMM * 3 * D, lambda: ops.gemm_bf16(
         h, bp['qkv'], qkv, EPI_QKV_ROTARY, rows_per_mod=L, rot_cos=p['cos'],
-        rot_sin=p['sin'], n_heads=H, m_rows_dev=n_rows_dev, ldc=0, M=M))
+        rot_sin=p['sin'], n_heads=H, m_rows_dev=n_rows_dev, ldc=0, M=M, tile=gt))
       T('attention', rows_t, 4.0 * L * D, lambda: ops.attn_fwd(
         q_, k_, vt_, ao, n_seq, H, L, n_seq_dev=n_active_dev))
       if tail_rows and bi == n_blocks - 1:
@@ -317,7 +322,7 @@ class DIT(nn.Module):
           x, xm, ao, aom, gather, n_rows_dev=live, rows=M))
         T('gemm_out', lt, GEMM * D, lambda: ops.gemm_bf16(
           aom, bp['out'], xm, EPI_GATE_RESIDUAL, gate=mod[:, 2 * D:3 * D],
-          residual=xm, rows_per_mod=L, n_mod=1, mod_ld=ld6, m_rows_dev=live, M=M))
+          residual=xm, rows_per_mod=L, n_mod=1, mod_ld=ld6, m_rows_dev=live, M=M, tile=gt))
         T('ln_modulate', lt, LN_B, lambda: ops.ln_modulate(
           xm, bp['n2'], mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D], h, L, 1, ld6, live))
         T('gemm_fc1', lt, GEMM * 4 * D, lambda: ops.gemm_bf16(
@@ -325,7 +330,7 @@ class DIT(nn.Module):
         T('gemm_fc2', lt, GEMM * 4 * D, lambda: ops.gemm_bf16(
           mh, bp['fc2'], xm, EPI_GATE_RESIDUAL, bias=bp['b2'],
           gate=mod[:, 5 * D:6 * D], residual=xm, rows_per_mod=L, n_mod=1,
-          mod_ld=ld6, m_rows_dev=live, M=M))
+          mod_ld=ld6, m_rows_dev=live, M=M, tile=gt))
         fm = mods[-1]
         T('ln_modulate', lt, LN_B, lambda: ops.ln_modulate(
           xm, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, 1, ld2, live))
@@ -340,7 +345,7 @@ class DIT(nn.Module):
       T('gemm_out', rows_t, GEMM * D, lambda: ops.gemm_bf16(
         ao, bp['out'], x, EPI_GATE_RESIDUAL, gate=mod[:, 2 * D:3 * D],
         residual=x, rows_per_mod=L, n_mod=n_mod, mod_ld=ld6,
-        m_rows_dev=n_rows_dev, M=M))
+        m_rows_dev=n_rows_dev, M=M, tile=gt))
       T('ln_modulate', rows_t, LN_B, lambda: ops.ln_modulate(
         x, bp['n2'], mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D], h, L, n_mod, ld6,
         n_rows_dev))
@@ -349,7 +354,7 @@ class DIT(nn.Module):
       T('gemm_fc2', rows_t, GEMM * 4 * D, lambda: ops.gemm_bf16(
         mh, bp['fc2'], x, EPI_GATE_RESIDUAL, bias=bp['b2'],
         gate=mod[:, 5 * D:6 * D], residual=x, rows_per_mod=L,
-        n_mod=n_mod, mod_ld=ld6, m_rows_dev=n_rows_dev, M=M))
+        n_mod=n_mod, mod_ld=ld6, m_rows_dev=n_rows_dev, M=M, tile=gt))
     if hidden_out is not None:
       ops.scatter_rows_f32(x, hidden_out, active, L, n_rows_dev=n_rows_dev)
       return None
