@@ -1,0 +1,7 @@
+#!/bin/bash
+# same-box comparison of several bench configurations: ab_bench_n.sh "<flags A>" "<flags B>" ...
+for i in 1 2; do
+  for v in "$@"; do
+    timeout -k 10 300 python -u bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-policy-compare --no-eval --profile-stride 0 $v 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[$v]', d['value'], d['ms_per_denoise_step'])" || exit 1
+  done
+done
