@@ -381,22 +381,25 @@ class Diffusion(_Base):
     and DiT workspace; group 0 runs on the caller's stream."""
     B, Lq = st['B'], st['L']
     G = int(self.config.sampling.get('stream_groups', 1))
-    if (aon or G < 2 or B % G or ((B // G) * Lq) % 256 or self._profile is not None
-        or bool(self.config.sampling.get('lazy_unmask', False))):
-      G = 1
+    # near-equal ranges (the first B % G take one sample more); the masked-row
+    # projection needs every range to hold a multiple of 256 rows
+    sizes = [B // max(G, 1) + (1 if g < B % max(G, 1) else 0) for g in range(max(G, 1))]
+    if (aon or G < 2 or min(sizes) < 1 or any((n * Lq) % 256 for n in sizes)
+        or self._profile is not None or bool(self.config.sampling.get('lazy_unmask', False))):
+      G, sizes = 1, [B]
     if st.get('groups') is not None and len(st['groups']) == G:
       return st['groups']
     dev = st['dev']
     i32 = dict(dtype=torch.int32, device=dev)
-    nb = B // G
     groups = []
     for g in range(G):
+      nb, s0 = sizes[g], sum(sizes[:g])
       if G == 1:
         grp = dict(g=0, s0=0, nb=B, active=st['active'], n_active=st['n_active'], n_rows=st['n_rows'],
                    gather=st['gather'], scatter=st['scatter'], n_mrows=st['n_mrows'])
       else:
         n_map = ops.workspace_bytes('masked_row_map', nb * Lq, 256) // 4
-        grp = dict(g=g, s0=g * nb, nb=nb, active=torch.zeros(nb, **i32),
+        grp = dict(g=g, s0=s0, nb=nb, active=torch.zeros(nb, **i32),
                    n_active=torch.zeros(1, **i32), n_rows=torch.zeros(1, **i32),
                    gather=torch.zeros(n_map, **i32), scatter=torch.zeros(n_map, **i32),
                    n_mrows=torch.zeros(1, **i32),
