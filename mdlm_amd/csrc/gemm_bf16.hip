@@ -308,6 +308,10 @@ __device__ __forceinline__ void epilogue_sub(const f32x4 (&accf)[MT][4], char* e
     int64_t orow0 = grow0;
     if constexpr (EPI == MDLM_EPI_STORE) {
       if (g.out_sample_map) {
+        // Rows past the live count of a partly live tile (samples shorter than the
+        // tile) belong to list entries past n_active: stale sample ids, whose cached
+        // rows must not be touched.  (rows_per_mod % 64 == 0: a sub-tile is all live or all dead.)
+        if (g.m_rows_dev && grow0 >= (int64_t)*g.m_rows_dev) return;
         const int64_t sidx = grow0 / g.rows_per_mod;
         orow0 = (int64_t)g.out_sample_map[sidx] * g.rows_per_mod + (grow0 - sidx * g.rows_per_mod);
       }

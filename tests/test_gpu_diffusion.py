@@ -194,6 +194,13 @@ def test_stream_groups_are_result_identical(ops):
     assert torch.equal(outs[0][0], o[0]) and outs[0][1] == o[1]
     assert outs[0][2] == o[2]
   assert (outs[0][0] != MASK).all()
+  # the other cache-refresh variants under two groups: every row projected; row lse in the update kernel
+  for ov in ('sampling.masked_rows_only=false', 'sampling.lse_from_gemm=false'):
+    model, cfg, _ = make_model(['sampling.stream_groups=2', 'loader.eval_batch_size=8', ov])
+    model.seed_rng(11)
+    x = model._sample(num_steps=40).cpu()
+    assert len(model._state['groups']) == 2
+    assert torch.equal(outs[0][0], x) and outs[0][1] == int(model.last_nfe.item()), ov
   # a batch that does not split into 256-row multiples falls back to one group
   model, cfg, _ = make_model(['sampling.stream_groups=2', 'loader.eval_batch_size=3'])
   model.seed_rng(11)

@@ -429,3 +429,28 @@ def test_gemm_half_tile_tail_is_bit_identical(ops):
   assert torch.equal(res[0][0][n_live * L:], x0[n_live * L:])      # rows past the live count untouched
   ref = x0[:4096] + mod[:, :D] * (h[:4096].float() @ Wo.float().T)
   assert _rel(res[0][0][:4096].cpu(), ref.cpu()) < 1e-2
+
+
+def test_gemm_sample_scatter_leaves_dead_rows_of_a_partly_live_tile_alone(ops):
+  """STORE epilogue with out_sample_map and samples shorter than a tile (L = 128,
+  256-row tiles): with 3 live samples the second tile is half dead, and its dead
+  half belongs to list entry 3 -- a stale sample id.  That sample's rows must
+  keep their cached contents (found by the stream-group test: a cached sample's
+  logits were overwritten from a dead workspace slot)."""
+  from mdlm_amd._lib import EPI_STORE
+  torch.manual_seed(3)
+  L, D, N, n_max = 128, 256, 512, 4
+  M = n_max * L
+  h = _bf(torch.randn(M, D)).cuda()
+  W = _bf(torch.randn(N, D) * 0.05).cuda()
+  amap = torch.tensor([5, 0, 2, 7], dtype=torch.int32).cuda()     # entry 3 (sample 7) is stale
+  live = torch.tensor([3 * L], dtype=torch.int32).cuda()
+  for tile in (0, 1):
+    out = torch.full((8 * L, N), 9.0, dtype=torch.bfloat16).cuda()
+    ops.gemm_bf16(h, W, out, EPI_STORE, rows_per_mod=L, m_rows_dev=live, out_sample_map=amap, tile=tile)
+    ref = (h.float() @ W.float().T).view(n_max, L, N)
+    o = out.float().view(8, L, N)
+    for slot, sample in enumerate((5, 0, 2)):
+      assert _rel(o[sample].cpu(), ref[slot].cpu()) < 1e-2
+    for sample in (1, 3, 4, 6, 7):
+      assert (o[sample] == 9.0).all(), (tile, sample)
