@@ -208,6 +208,31 @@ def test_stream_groups_are_result_identical(ops):
   assert len(model._state['groups']) == 1
 
 
+def test_result_identical_knobs_agree_on_small_shapes(ops):
+  """Every combination of the result-identical knobs (cache policy, stream groups,
+  masked-row projection, row lse from the GEMM epilogue, race evaluation) emits the
+  tokens of the plainest configuration -- no cache, one stream, every row
+  projected, lse inside the update kernel, reference race -- on shapes where a
+  sample is shorter than a GEMM tile and the batch does not split evenly."""
+  import itertools
+  for B, L, steps in ((8, 128, 48), (5, 128, 30), (6, 256, 40)):
+    combos = [dict(cache_policy='none', stream_groups=1, masked_rows_only='false',
+                   lse_from_gemm='false', fast_math='false')]
+    for cp, g, mr, lg in itertools.product(('sample', 'batch'), (1, 2, 3), ('true', 'false'),
+                                           ('true', 'false')):
+      combos.append(dict(cache_policy=cp, stream_groups=g, masked_rows_only=mr, lse_from_gemm=lg,
+                         fast_math='true'))
+    base = None
+    for c in combos:
+      ov = [f'sampling.{k}={v}' for k, v in c.items()]
+      model, cfg, _ = make_model(ov + [f'loader.eval_batch_size={B}', f'model.length={L}'])
+      model.seed_rng(21)
+      x = model._sample(num_steps=steps).cpu()
+      if base is None:
+        base = x
+      assert torch.equal(base, x), (B, L, c)
+
+
 def test_time_conditioning_path(ops):
   model, cfg, p = make_model(['time_conditioning=true'])
   model.seed_rng(9)
