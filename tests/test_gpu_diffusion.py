@@ -233,6 +233,52 @@ def test_result_identical_knobs_agree_on_small_shapes(ops):
       assert torch.equal(base, x), (B, L, c)
 
 
+def test_state_reuse_across_calls(ops):
+  """One model runs sampling, semi-AR generation, the loss, the API-level cached
+  update and forward in sequence (they share the sampler / eval state, the stream
+  groups and the DiT workspaces); every result equals that of a fresh model given
+  the same Philox seed."""
+  B, L = 8, 128
+  ov = [f'loader.eval_batch_size={B}', f'model.length={L}']
+  torch.manual_seed(0)
+  x0 = torch.randint(0, V - 1, (B, L)).cuda()
+  tt = (torch.rand(B) * 0.98 + 0.01).cuda()
+  u = torch.rand(B, L).cuda()
+  xt = x0.clone(); xt[torch.rand(B, L).cuda() < 0.5] = MASK
+
+  def calls(model):
+    def sample40():
+      model.seed_rng(1); return model._sample(num_steps=40).cpu()
+    def semi():
+      model.seed_rng(2)
+      return model.sample_subs_guidance(n_samples=B, stride_length=64, num_strides=1, dt=1 / 16)[1]
+    def sample24():
+      model.seed_rng(3); return model._sample(num_steps=24).cpu()
+    def loss():
+      return model._loss(x0, None, t=tt, u=u).nlls.float().cpu()
+    def api():
+      model.seed_rng(4)
+      p, xn = model._ddpm_caching_update(xt, torch.full((B, 1), 0.5).cuda(), 0.01)
+      return model._ddpm_caching_update(xn, torch.full((B, 1), 0.49).cuda(), 0.01, p_x0=p)[1].cpu()
+    def fwd():
+      return model.forward(xt, torch.zeros(B).cuda()).float().cpu()
+    return dict(sample40=sample40, semi=semi, sample24=sample24, loss=loss, api=api, fwd=fwd)
+
+  ref = {}
+  for name in ('sample40', 'semi', 'sample24', 'loss', 'api', 'fwd'):
+    ref[name] = calls(make_model(ov)[0])[name]()
+  fns = calls(make_model(ov)[0])
+  for name in ('sample40', 'semi', 'loss', 'sample24', 'api', 'fwd', 'semi', 'sample40', 'api', 'loss',
+               'sample24', 'fwd', 'sample40'):
+    out = fns[name]()
+    if not torch.is_tensor(out):
+      assert out == ref[name], name
+    elif out.dtype == torch.float32:
+      assert (out - ref[name]).abs().max() < 1e-5, name
+    else:
+      assert torch.equal(out, ref[name]), name
+
+
 def test_time_conditioning_path(ops):
   model, cfg, p = make_model(['time_conditioning=true'])
   model.seed_rng(9)
