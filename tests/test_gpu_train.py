@@ -331,6 +331,25 @@ def test_training_step_matches_oracle(ops, p_drop):
   assert _rel(lg, ref_lg) < 2e-2
 
 
+@pytest.mark.parametrize('B,L', [(3, 128), (5, 256), (16, 128)])
+def test_training_gradients_other_batch_shapes(ops, B, L):
+  """forward_backward against the oracle's autograd at row counts that are odd
+  multiples of 128 (128x128 GEMM tiles, partial split-K ranges) and at L = 256."""
+  model, cfg, p, tr = _make_trainer(0.0, extra=[f'model.length={L}', f'loader.eval_batch_size={B}'])
+  m = cfg.model
+  x0, attn, t, u = _batch(B, L, seed=B * 10 + L)
+  loss, nlls = tr.forward_backward(x0.cuda(), attn.cuda(), t=t.cuda(), u_xt=u.cuda())
+  ref_loss, ref_nlls, ref_g = orc.loss_and_grads(p, x0, attn, t, u, m.n_heads, m.n_blocks,
+                                                 MASK_T, None, 0.0)
+  assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item())
+  assert _rel(nlls, ref_nlls) < 2e-2
+  g = tr.grads()
+  flat = torch.cat([g[k].reshape(-1).cpu() for k in ref_g]).double()
+  flat_ref = torch.cat([ref_g[k].reshape(-1) for k in ref_g]).double()
+  assert ((flat @ flat_ref) / (flat.norm() * flat_ref.norm())).item() > 0.999
+  assert max(_rel(g[k], ref_g[k]) for k in ref_g) < 6e-2
+
+
 def test_training_reduces_loss_and_time_conditioning(ops):
   model, cfg, p, tr = _make_trainer(0.1, time_conditioning=True)
   B, L = 4, cfg.model.length
