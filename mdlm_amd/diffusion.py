@@ -32,7 +32,7 @@ import torch
 from . import dist as mdist
 from . import ops
 from .dit import DIT
-from .ema import ExponentialMovingAverage
+from .shadow import ShadowWeights
 from .noise_schedule import get_noise
 
 try:  # Lightning is optional; the reference derives from L.LightningModule
@@ -110,9 +110,7 @@ class Diffusion(_Base):
     self.test_metrics = MeanMetrics('test/')
     self.noise = get_noise(self.config)
     if self.config.training.ema > 0:
-      self.ema = ExponentialMovingAverage(
-        itertools.chain(self.backbone.parameters(), self.noise.parameters()),
-        decay=self.config.training.ema)
+      self.ema = ShadowWeights(self._params(), decay=self.config.training.ema)
     else:
       self.ema = None
     self.lr = self.config.optim.lr
@@ -162,9 +160,9 @@ class Diffusion(_Base):
   def on_load_checkpoint(self, checkpoint):  # diffusion.py:168-170
     if not self.ema:
       return
+    self.ema.to(self.device)
     if 'ema' in checkpoint:
       self.ema.load_state_dict(checkpoint['ema'])
-      self.ema.move_shadow_params_to_device(self.device)
       self._ema_restored = True
     else:
       # A file without an `ema` entry (plain state dict, .safetensors): the
@@ -172,8 +170,7 @@ class Diffusion(_Base):
       # restore_model_and_sample / validation would swap THOSE in over the
       # loaded ones.  The loaded weights are the only ones there are: re-seed
       # the shadow from them.
-      self.ema.shadow_params = [p.clone().detach() for p in self._params()
-                                if p.requires_grad]
+      self.ema.assign(p for p in self._params() if p.requires_grad)
       self.ema.num_updates = 0
       self._ema_restored = False
 
@@ -182,13 +179,12 @@ class Diffusion(_Base):
 
   def _ema_swap_in(self):
     if self.ema:
-      self.ema.store(self._params())
-      self.ema.copy_to(self._params())
+      self.ema.swap_in(self._params())
       self.backbone.refresh()
 
   def _ema_swap_out(self):
     if self.ema:
-      self.ema.restore(self._params())
+      self.ema.swap_out(self._params())
       self.backbone.refresh()
 
   # ------------------------------------------------------------- SUBS / forward

@@ -26,10 +26,11 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import dist as mdist
 from . import ops
 from ._lib import EPI_QKV_ROTARY, EPI_STORE
-
-_ALIGN = 64  # elements: every parameter view starts 256-byte aligned
+from .shadow import ALIGN as _ALIGN   # elements: every parameter view starts 256-byte aligned
+from .shadow import flat_layout
 
 
 def constant_warmup_lr(base_lr, step, num_warmup_steps):
@@ -112,17 +113,20 @@ class Trainer:
     self.num_warmup_steps = num_warmup_steps
     self.p_drop = float(bb.blocks[0].dropout if dropout is None else dropout)
     self.ema_decay = float(cfg.training.ema)
+    # Two counters, as in the reference: `step_count` is the optimizer's (Adam bias
+    # correction, lr warm-up; Lightning's global_step), `ema_updates` is
+    # models/ema.py's num_updates (decay warm-up).  They differ after a restart
+    # from a weights + EMA checkpoint without optimizer state.
     self.step_count = 0
+    self.ema_updates = 0
     self.group = group
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
     # ---- flat buffers ------------------------------------------------------
     named = list(bb.named_parameters())
     self.names = [n for n, _ in named]
-    self.offsets, off = {}, 0
-    for n, p in named:
-      self.offsets[n] = (off, p.numel(), tuple(p.shape))
-      off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+    table, off = flat_layout([p.shape for _, p in named])
+    self.offsets = {n: e for (n, _), e in zip(named, table)}
     self.n_flat = off
     z = lambda dt=torch.float32: torch.zeros(off, dtype=dt, device=dev)
     self.P, self.G, self.M1, self.M2 = z(), z(), z(), z()
@@ -135,16 +139,21 @@ class Trainer:
     self.W16.copy_(self.P)
     self.E = None
     if self.ema_decay > 0:
-      self.E = self.P.clone()
       ema = getattr(model, 'ema', None)
-      if ema:
-        # an EMA restored by on_load_checkpoint (diffusion.py:168-170) is kept:
-        # its shadow parameters move into the flat buffer, its update count
-        # continues the decay warm-up of models/ema.py:44-46
+      if ema is not None and ema.n_flat == self.n_flat:
+        # the model's shadow weights have this layout already: their buffer IS the
+        # optimizer kernel's EMA operand.  An EMA restored by on_load_checkpoint
+        # (diffusion.py:168-170) is kept and its update count continues the decay
+        # warm-up of models/ema.py:40-44; a constructor-time one restarts from the
+        # current weights.
+        self.E = ema.to(dev).flat
         if getattr(model, '_ema_restored', False):
-          for n, sp in zip(self.names, ema.shadow_params):
-            self._view(self.E, n).copy_(sp.to(dev))
-        ema.shadow_params = [self._view(self.E, n) for n in self.names]
+          self.ema_updates = int(ema.num_updates)
+        else:
+          self.E.copy_(self.P)
+          ema.num_updates = 0
+      else:
+        self.E = self.P.clone()
     bb.refresh()
     # DDP buckets in the order the backward completes them: output layer,
     # blocks L-1..0, then everything before block 0 (embedding, sigma_map)
@@ -177,7 +186,7 @@ class Trainer:
 
   def ema_state_dict(self):
     """models/ema.py:89-92 layout."""
-    return dict(decay=self.ema_decay, num_updates=self.step_count,
+    return dict(decay=self.ema_decay, num_updates=self.ema_updates,
                 shadow_params=[self._view(self.E, n) for n in self.names])
 
   # -------------------------------------------------------------- checkpoints
@@ -186,8 +195,12 @@ class Trainer:
     shadow, optimizer-step count and the Philox stream position (the reference
     gets these from Lightning's checkpoint: optimizer_states, loops, and the
     `ema` entry written by on_save_checkpoint, diffusion.py:172-181)."""
+    # the Philox key is stored rank-free: every rank of a resumed DDP run loads
+    # rank 0's file and must get back ITS OWN stream (seed + rank), not rank 0's
+    rank = mdist.env_rank()[0]
     return dict(P=self.P, M1=self.M1, M2=self.M2, E=self.E, step_count=self.step_count,
-                rng_seed=self.model._rng_seed, rng_offset=self.model._rng_offset,
+                ema_updates=self.ema_updates,
+                rng_seed=self.model._rng_seed - rank, rng_offset=self.model._rng_offset,
                 n_flat=self.n_flat)
 
   def load_state_dict(self, sd):
@@ -198,9 +211,11 @@ class Trainer:
       self.E.copy_(sd['E'])
     self.W16.copy_(self.P)
     self.step_count = int(sd['step_count'])
-    self.model.seed_rng(int(sd['rng_seed']), int(sd['rng_offset']))
-    if getattr(self.model, 'ema', None):
-      self.model.ema.num_updates = self.step_count
+    self.ema_updates = int(sd.get('ema_updates', self.step_count))
+    self.model.seed_rng(mdist.rank_seed(int(sd['rng_seed']), mdist.env_rank()[0]),
+                        int(sd['rng_offset']))
+    if getattr(self.model, 'ema', None) is not None:
+      self.model.ema.num_updates = self.ema_updates
     self.bb.refresh()
 
   def save_checkpoint(self, path):
@@ -214,7 +229,7 @@ class Trainer:
             'trainer_state': {k: (v.detach().clone() if torch.is_tensor(v) else v)
                               for k, v in self.state_dict().items()}}
     if self.E is not None:
-      ckpt['ema'] = dict(decay=self.ema_decay, num_updates=self.step_count,
+      ckpt['ema'] = dict(decay=self.ema_decay, num_updates=self.ema_updates,
                          shadow_params=[self._view(self.E, n).detach().clone() for n in self.names])
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     tmp = path + '.tmp'
@@ -225,7 +240,10 @@ class Trainer:
     ckpt = torch.load(path, map_location=self.dev, weights_only=True)
     if 'trainer_state' in ckpt:
       self.load_state_dict(ckpt['trainer_state'])
-    else:  # a reference checkpoint: weights (+ EMA) only, optimizer state starts fresh
+    else:
+      # a reference checkpoint: weights (+ EMA) only.  There are no Adam moments
+      # in it, so the optimizer starts fresh -- step count, bias correction and lr
+      # warm-up at 0 -- and only the EMA's own update count carries over.
       bbsd = {k[len('backbone.'):]: v for k, v in ckpt['state_dict'].items()
               if k.startswith('backbone.')}
       for n in self.names:
@@ -235,10 +253,16 @@ class Trainer:
         if 'ema' in ckpt:
           for n, sp in zip(self.names, ckpt['ema']['shadow_params']):
             self._view(self.E, n).copy_(sp)
-          self.step_count = int(ckpt['ema'].get('num_updates', 0))
+          self.ema_updates = int(ckpt['ema'].get('num_updates', 0) or 0)
         else:
           self.E.copy_(self.P)
+          self.ema_updates = 0
+        if getattr(self.model, 'ema', None) is not None:
+          self.model.ema.num_updates = self.ema_updates
+      self.M1.zero_(); self.M2.zero_()
+      self.step_count = 0
       self.bb.refresh()
+      return 0
     return ckpt.get('global_step', self.step_count)
 
   def _workspace(self, B, L):
@@ -373,7 +397,7 @@ class Trainer:
     if M % 128 or L % 64 or D % 128:
       raise ValueError('Trainer: B*L must be a multiple of 128, L of 64, hidden of 128')
     ws = self._workspace(B, L)
-    ops.check_token_ids(x0, V)
+    lo_hi = torch.stack(torch.aminmax(x0)).to(torch.int64)   # device; read with n_pad below
     if attention_mask is None:
       attention_mask = torch.ones(B, L, dtype=torch.float32, device=self.dev)
     attention_mask = attention_mask.float()
@@ -385,7 +409,14 @@ class Trainer:
     xt = model.q_xt(x0, move_chance, u=u_xt)
     ops.masked_row_map(xt, ws['samples'], ws['n_samples'], L, model.mask_index,
                        ws['gather'], ws['scatter'], ws['n_out'], pad=256)
-    n_pad = int(ws['n_out'].item())   # the only host read of the step (GPU queue still empty)
+    # the only host read of the step (GPU queue still empty): the padded masked-row
+    # count and the id range of x0 (ids outside the vocabulary raise, as the
+    # reference's embedding lookup does, dit.py:298-299; nothing has consumed them yet
+    # except q_xt / the row map, which only compare them with mask_index)
+    n_pad, lo, hi = torch.cat([ws['n_out'].to(torch.int64), lo_hi]).tolist()
+    if lo < 0 or hi >= V:
+      raise IndexError(f'token id out of range: min {lo}, max {hi}, vocabulary size {V} '
+                       '(tokenizer / checkpoint mismatch?)')
     sig_in = model._process_sigma(sigma[:, None])
     n_mod = B if model.time_conditioning else 1
     with torch.enable_grad():
@@ -542,12 +573,16 @@ class Trainer:
     self.last_lr = lr
     self.last_grad_norm = self._sumsq  # device: sum of squares of the summed grads
     n = self.step_count
-    omd = 1.0 - min(self.ema_decay, (1 + n) / (10 + n)) if self.E is not None else 0.0
+    omd = 0.0
+    if self.E is not None:   # models/ema.py:40-45 on the EMA's own counter
+      self.ema_updates += 1
+      ne = self.ema_updates
+      omd = 1.0 - min(self.ema_decay, (1 + ne) / (10 + ne))
     ops.adamw_ema(self.P, self.G, self.M1, self.M2, self.E, self.W16, lr, self.betas[0],
                   self.betas[1], self.eps, self.weight_decay, n, omd, sumsq=self._sumsq,
                   max_norm=self.max_norm or 0.0, grad_scale=scale)
-    if getattr(self.model, 'ema', None):
-      self.model.ema.num_updates = n
+    if getattr(self.model, 'ema', None) is not None:
+      self.model.ema.num_updates = self.ema_updates
     self.bb.refresh()
     return lr
 

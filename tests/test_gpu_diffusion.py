@@ -687,6 +687,23 @@ def test_checkpoint_ingestion(ops, tmp_path):
   assert torch.equal(with_ema, m3.restore_model_and_sample(num_steps=8))
 
 
+def _full_size_model(B, overrides=()):
+  """DiT-small (12 blocks, D = 768, 12 heads), L = 1024, V = 50,258 with the
+  oracle's seeded synthetic weights: BASELINE configs[1] at its real size."""
+  from mdlm_amd.config import load_config
+  from mdlm_amd.diffusion import Diffusion
+  from mdlm_amd.tokenizer import SyntheticTokenizer
+  Vf = 50258
+  cfg = load_config(['model=small', f'loader.eval_batch_size={B}', 'sampling.steps=1000', *overrides])
+  model = Diffusion(cfg, SyntheticTokenizer(vocab_size=Vf - 1)).cuda()
+  m = cfg.model
+  p = orc.synthetic_dit_params(m.hidden_size, m.n_heads, m.n_blocks, m.cond_dim, Vf, seed=1)
+  sd = dict(p); sd['rotary_emb.inv_freq'] = model.backbone.rotary_emb.inv_freq
+  model.backbone.load_state_dict(sd)
+  model.ema = None
+  return model, cfg, p
+
+
 def test_full_size_configs1_backbone_and_fused_step(ops):
   """BASELINE configs[1] at its real size, B = 1: DiT-small (12 blocks, D = 768,
   12 heads), L = 1024, V = 50,258 (reference models/dit.py:359-370,
@@ -695,17 +712,9 @@ def test_full_size_configs1_backbone_and_fused_step(ops):
   the gathered rows, the 197th (82-column) vocabulary tile and the row scatter
   into the cache give bit-identical logits to the plain forward; (3) the step's
   tokens equal the oracle race on those logits and the same Philox uniforms."""
-  from mdlm_amd.config import load_config
-  from mdlm_amd.diffusion import Diffusion
-  from mdlm_amd.tokenizer import SyntheticTokenizer
   Vf, Mf = 50258, 50257
-  cfg = load_config(['model=small', 'loader.eval_batch_size=1', 'sampling.steps=1000'])
-  model = Diffusion(cfg, SyntheticTokenizer(vocab_size=Vf - 1)).cuda()
+  model, cfg, p = _full_size_model(1)
   m = cfg.model
-  p = orc.synthetic_dit_params(m.hidden_size, m.n_heads, m.n_blocks, m.cond_dim, Vf, seed=1)
-  sd = dict(p); sd['rotary_emb.inv_freq'] = model.backbone.rotary_emb.inv_freq
-  model.backbone.load_state_dict(sd)
-  model.ema = None
   L = m.length
   torch.manual_seed(4)
   x = torch.randint(0, Vf - 1, (1, L))
@@ -770,3 +779,93 @@ def test_full_size_trajectory_modes_agree(ops):
   assert torch.equal(outs[0], outs[1])
   assert torch.equal(outs[0], outs[2])
   assert torch.equal(outs[0], outs[3])
+
+
+def test_full_size_default_loop_matches_oracle_loop(ops):
+  """The DEFAULT sampling loop at BASELINE configs[1]'s real size against the
+  ORACLE loop (not against another HIP mode): DiT-small, L = 1024, V = 50,258,
+  B = 2, several denoising steps late in the schedule from a mostly unmasked
+  start, so that in some steps a sample's tokens do not change and its cached
+  logits are reused while the other sample is re-evaluated.  Everything the
+  default configuration combines is live: fast race, per-sample cache, masked-row
+  projection with row scatter into the cache, row lse from the vocabulary GEMM's
+  epilogue, two stream groups (one sample each).  The oracle runs the reference
+  loop literally (diffusion.py:674-686, 592-610: all-or-nothing cache,
+  `_sample_categorical` on fp32 SUBS probabilities) on the GPU backbone's
+  logits and the same Philox uniforms; tokens must be equal after every step."""
+  Vf, Mf = 50258, 50257
+  B, n_steps = 2, 7
+  model, cfg, p = _full_size_model(B)
+  assert cfg.sampling.get('stream_groups', 1) == 2 and cfg.sampling.get('fast_math', False)
+  assert cfg.sampling.get('cache_policy', 'sample') == 'sample'
+  m = cfg.model
+  L = m.length
+  g = torch.Generator().manual_seed(11)
+  x0 = torch.randint(0, Vf - 1, (B, L), generator=g)
+  # 14 / 9 masked positions: P(no token of a sample changes in a step) = (1 - dt/t)^n
+  for b, n in enumerate((14, 9)):
+    x0[b, torch.randperm(L, generator=g)[:n]] = Mf
+  T = 1000
+  dt = (1 - 1e-5) / T
+  timesteps = torch.linspace(1, 1e-5, T + 1)
+  first = T - 20                       # t = 0.02: dt / t = 0.05 per masked position and step
+  st = model._sampler_state(B, L)
+  assert len(model._stream_groups(st, False)) == 2
+  x, x_next = st['xa'], st['xb']
+  x.copy_(x0.cuda()); st['changed'].fill_(1); st['nfe'].zero_()
+  model.seed_rng(321)
+  od = GpuBackedOracle(model, ops, p, m.n_heads, m.n_blocks, Vf, Mf, L)
+  od.seed = 321
+  od.rand = lambda *shape: od.draw(*shape)
+  xr, cache = x0.clone(), None
+  hits = changes = 0
+  for i in range(first, first + n_steps):
+    t = timesteps[i] * torch.ones(B, 1)
+    model._fused_step(st, x, x_next, t.squeeze(-1).cuda(), dt)
+    x, x_next = x_next, x
+    hits += cache is not None
+    cache, xn = od._ddpm_caching_update(xr, t, dt, p_x0=cache)
+    if not torch.allclose(xn, xr):                      # diffusion.py:682-685
+      cache = None
+      changes += 1
+    xr = xn
+    assert torch.equal(x.cpu(), xr), f'step {i}'
+  # the run exercised both branches of the cache, and the per-sample policy did
+  # strictly less backbone work than the oracle's all-or-nothing policy
+  assert changes >= 2 and int((xr == Mf).sum()) < 23
+  nfe = int(st['nfe'].item())
+  assert B <= nfe < od.nfe * B or hits > 0, (nfe, od.nfe, hits)
+  assert nfe <= od.nfe * B
+
+
+def test_full_size_loss_matches_oracle(ops):
+  """`_loss` (diffusion.py:896-916, 847-894) at the real size, B = 1: q_xt ->
+  backbone with the vocabulary projection on the masked rows only -> row lse out
+  of the GEMM epilogue -> `mdlm_subs_nll(row_lse=...)`, against the fp32 CPU
+  oracle's `_loss` on the same x0, t and q_xt uniforms.  Tolerances: per-token
+  NLL within 2e-2 relative (bf16 logits), token NLL (hence perplexity, its exp)
+  within 0.5 %."""
+  Vf, Mf = 50258, 50257
+  model, cfg, p = _full_size_model(1)
+  m = cfg.model
+  L = m.length
+  assert cfg.sampling.get('lse_from_gemm', True) and cfg.sampling.get('masked_rows_only', True)
+  g = torch.Generator().manual_seed(5)
+  x0 = torch.randint(0, Vf - 1, (1, L), generator=g)
+  x0[0, 0] = x0[0, -1] = Vf - 2                       # BOS / EOS wrap (dataloader.py:286-296)
+  attn = torch.ones(1, L); attn[0, -7:] = 0
+  t = torch.tensor([0.37])
+  u = torch.rand(1, L, generator=g)
+  loss = model._loss(x0.cuda(), attn.cuda(), t=t.cuda(), u=u.cuda())
+  assert model._eval_state is not None and int(model._eval_state['n_mrows'].item()) > 256
+  od = orc.OracleDiffusion(p, m.n_heads, m.n_blocks, Vf, Mf, L)
+  with torch.no_grad():
+    tok_ref, nll_ref, _ = od._loss(x0, attn, t=t, u_xt=u)
+  got = loss.nlls.cpu()
+  live = nll_ref != 0
+  assert torch.equal(got != 0, live)                   # unmasked / padded positions: exactly 0
+  assert 300 < int(live.sum()) < 450
+  rel = ((got - nll_ref).abs() / nll_ref.abs().clamp(min=1.0))[live]
+  assert rel.max().item() < 2e-2, rel.max().item()
+  # perplexity = exp(token NLL) (diffusion.py:58-65): within 0.5 %
+  assert abs(math.exp(loss.loss.item() - tok_ref.item()) - 1) < 5e-3, (loss.loss.item(), tok_ref.item())

@@ -640,6 +640,50 @@ def test_trainer_checkpoint_roundtrip_and_resume(ops, tmp_path):
   tr4 = Trainer(m4, lr=3e-3, num_warmup_steps=2, dropout=0.1)
   for n, sp in zip(tr4.names, ckpt['ema']['shadow_params']):
     assert torch.equal(tr4._view(tr4.E, n).cpu(), sp), n
+  # ... and CONTINUES it: the next update uses the decay of update 4 of
+  # models/ema.py:40-45 (min(0.999, 5/14)), not a restarted warm-up (2/11) --
+  # while the optimizer, which got no Adam moments from this loader, starts at 0
+  assert tr4.ema_updates == 3 and tr4.step_count == 0
+  e0 = tr4.E.clone()
+  step(tr4, batches[3])
+  d = min(0.999, (1 + 4) / (10 + 4))
+  want = e0 - (1 - d) * (e0 - tr4.P)
+  assert torch.allclose(tr4.E, want, rtol=1e-5, atol=1e-7), (tr4.E - want).abs().max().item()
+  assert tr4.ema_updates == 4 and tr4.step_count == 1 and m4.ema.num_updates == 4
+  assert tr4.ema_state_dict()['num_updates'] == 4
+
+  # a weights + EMA file WITHOUT optimizer state through Trainer.load_checkpoint
+  # (a reference checkpoint): only the EMA's counter carries over
+  ref_like = {k: v for k, v in ckpt.items() if k != 'trainer_state'}
+  ref_like['ema'] = dict(ckpt['ema'], num_updates=100000)
+  path_ref = str(tmp_path / 'ref_like.ckpt')
+  torch.save(ref_like, path_ref)
+  model5, _, _, tr5 = _make_trainer(0.1, seed=13, extra=['training.ema=0.999'])
+  step(tr5, batches[0])   # dirty Adam moments / counters that the load must reset
+  assert tr5.load_checkpoint(path_ref) == 0
+  assert tr5.step_count == 0 and tr5.ema_updates == 100000
+  assert float(tr5.M1.abs().max()) == 0 and float(tr5.M2.abs().max()) == 0
+  e0 = tr5.E.clone()
+  step(tr5, batches[3])
+  assert tr5.last_lr == 0.0      # optimizer step 0 of the warm-up: lr 0 (constant_warmup)
+  want = e0 - (1 - 0.999) * (e0 - tr5.P)
+  assert torch.allclose(tr5.E, want, rtol=1e-5, atol=1e-7)
+
+  # every rank of a resumed DDP run loads rank 0's file; each must get back its
+  # OWN Philox key (seed + rank), not rank 0's
+  import os
+  old = os.environ.get('RANK')
+  os.environ['RANK'] = '1'
+  try:
+    model6, _, _, tr6 = _make_trainer(0.1, seed=11, extra=['training.ema=0.999'])
+    tr6.load_checkpoint(path)
+    assert model6._rng_seed == model2._rng_seed + 1
+    assert model6._rng_offset == ckpt['trainer_state']['rng_offset']
+  finally:
+    if old is None:
+      del os.environ['RANK']
+    else:
+      os.environ['RANK'] = old
 
 
 def test_trainer_rejects_discrete_time_and_bad_ids(ops):
