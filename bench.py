@@ -17,10 +17,11 @@ is the CPU oracle timed on this box's host cores on a bounded sample; `dist`
 records the backend, the world size and an all-reduce check.
 `python bench.py --gpus N` without torchrun starts its own N ranks.
 
-Other workloads of BASELINE.json's config list, each printing its own JSON line
-(never the driver's default): `--workload train` (configs[4], LM1B training
-step tokens/s) and `--workload semi_ar` (configs[3], 2048-token semi-AR
-sequences/s).  `MDLM_DIST_BACKEND=gloo` rehearses N ranks on a one-GPU box.
+The other workloads of BASELINE.json's config list ride in the same line as
+sub-blocks, each with its own value / unit / config / dominant-kernel roofline:
+`eval` (configs[2], NELBO tokens/s), `semi_ar` (configs[3], one batch of 2048-token
+semi-AR sequences on the same model) and `train` (configs[4], 20 LM1B training
+steps on its own model); `--workload train | semi_ar` runs one of them alone.  `MDLM_DIST_BACKEND=gloo` rehearses N ranks on a one-GPU box.
 """
 import argparse
 import json
@@ -38,6 +39,37 @@ from mdlm_amd.config import load_config  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+
+
+def csrc_sha16():
+  """sha256 (first 16 hex digits) over the kernel sources: stamps the PMC traffic
+  figures (tools/pmc_traffic.py writes it, this file compares it), so that bytes
+  measured on other kernels are never replayed as this tree's."""
+  import glob
+  import hashlib
+  h = hashlib.sha256()
+  d = os.path.join(ROOT, 'mdlm_amd', 'csrc')
+  for f in sorted(glob.glob(os.path.join(d, '*.hip')) + glob.glob(os.path.join(d, '*.h'))):
+    h.update(os.path.basename(f).encode())
+    h.update(open(f, 'rb').read())
+  return h.hexdigest()[:16]
+
+
+def load_traffic():
+  """profiles/pmc_traffic.json if it was collected on THIS tree's kernels, else no
+  per-kernel traffic (null in the rooflines) and the reason."""
+  tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+  if not os.path.exists(tpath):
+    return {}, {'file': None, 'used': False, 'why': 'profiles/pmc_traffic.json absent'}
+  t = json.load(open(tpath))
+  src = {'file': 'profiles/pmc_traffic.json', 'git_head': t.get('_git_head'),
+         'collected': t.get('_date'), 'T': t.get('_T'), 'csrc_sha16': t.get('_csrc_sha16'),
+         'tree_csrc_sha16': csrc_sha16()}
+  src['used'] = src['csrc_sha16'] == src['tree_csrc_sha16']
+  if not src['used']:
+    src['why'] = 'kernel sources changed since the PMC passes: traffic dropped (null), not replayed'
+    return {}, src
+  return t, src
 
 
 def synthetic_state_dict(model_cfg, vocab, seed=1):
@@ -136,19 +168,78 @@ def cpu_baseline(cfg, T, budget_s=20.0):
   }
 
 
-def train_bench(args):
+class OpTimer:
+  """HIP events on the launch stream around every call of the public functions of
+  `mdlm_amd.ops` (the training step's kernels), for ONE profiling step outside the
+  timed region.  name -> [(start, end, work)], work = algorithmic flops of the
+  GEMM / attention calls (from their operand shapes), else None."""
+
+  GEMMS = {'gemm_bf16': lambda a, w, *r, **k: 2.0 * a.shape[0] * w.shape[0] * w.shape[1],
+           'gemm_bf16_gelu': lambda a, w, *r, **k: 2.0 * a.shape[0] * w.shape[0] * w.shape[1],
+           # dW = dY^T X over T tokens: (T, N) x (T, K)
+           'gemm_tn_splitk': lambda dy, a, *r, **k: 2.0 * dy.shape[0] * dy.shape[1] * a.shape[1],
+           'gemm_bf16_splitk': lambda a, w, *r, **k: 2.0 * a.shape[0] * w.shape[0] * a.shape[1]}
+
+  def __init__(self):
+    from mdlm_amd import ops
+    self.ops, self.saved, self.events = ops, {}, {}
+
+  def __enter__(self):
+    import types
+    for name, fn in vars(self.ops).items():
+      if name.startswith('_') or not isinstance(fn, types.FunctionType) or fn.__module__ != self.ops.__name__:
+        continue
+      if name in ('workspace', 'workspace_bytes', 'check_token_ids', 'splitk_plan', 'tn_splitk_plan',
+                  'padded_vocab', 'alloc_logits', 'gemm_set_tile'):
+        continue
+      self.saved[name] = fn
+      setattr(self.ops, name, self._wrap(name, fn))
+    return self
+
+  def _wrap(self, name, fn):
+    def timed(*a, **k):
+      e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+      e0.record()
+      r = fn(*a, **k)
+      e1.record()
+      work = self.GEMMS[name](*a, **k) if name in self.GEMMS else None
+      self.events.setdefault(name, []).append((e0, e1, work))
+      return r
+    return timed
+
+  def __exit__(self, *exc):
+    for name, fn in self.saved.items():
+      setattr(self.ops, name, fn)
+
+  def summary(self, extra_work=None):
+    """[{op, launches, total_ms, avg_launch_ms, (achieved, peak, frac)}], by total time."""
+    torch.cuda.synchronize()
+    out = []
+    for name, evs in self.events.items():
+      ms = [a.elapsed_time(b) for a, b, _ in evs]
+      d = {'op': name, 'launches': len(ms), 'total_ms': round(sum(ms), 3),
+           'avg_launch_ms': round(sum(ms) / len(ms), 4)}
+      work = [w for _, _, w in evs]
+      if extra_work and name in extra_work:
+        work = [extra_work[name]] * len(evs)
+      if all(w is not None for w in work) and sum(ms) > 0:
+        ach = sum(work) / (sum(ms) * 1e-3) / 1e12
+        d.update(bound='mfma', achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
+                 frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                 algorithmic_gflop_per_launch=round(sum(work) / len(work) / 1e9, 2))
+      out.append(d)
+    return sorted(out, key=lambda d: -d['total_ms'])
+
+
+def train_block(steps, warmup, global_batch, rank, world, dev, profile=True):
   """BASELINE.json configs[4]: LM1B MDLM training step, DiT-small, L=128, global
   batch 512 split over the ranks (strong scaling), bert-base-uncased-shaped
   vocabulary (30,522, [MASK]=103 in-vocabulary), dropout 0.1, clip 1.0, AdamW,
   EMA, DDP gradient all-reduce on RCCL overlapped with the backward.  A step =
   forward + backward + all-reduce + optimizer/EMA over one global batch."""
   from mdlm_amd.train import Trainer
-  rank, local_rank, world = mdist.init()
-  torch.cuda.set_device(mdist.local_device(local_rank))
-  dev = torch.device('cuda', mdist.local_device(local_rank))
-  gb = args.global_batch
   cfg = load_config(['model=small', 'data=lm1b', 'model.length=128',
-                     f'loader.global_batch_size={gb}', f'trainer.devices={world}'])
+                     f'loader.global_batch_size={global_batch}', f'trainer.devices={world}'])
   model = build_model(cfg, seed=1)   # same weights on every rank
   model.seed_rng(mdist.rank_seed(cfg.seed, rank))
   tr = Trainer(model, num_warmup_steps=cfg.lr_scheduler.num_warmup_steps)
@@ -159,10 +250,9 @@ def train_bench(args):
   ids[:, 0] = 101; ids[:, -1] = 102
   batch = {'input_ids': ids, 'attention_mask': torch.ones(B, L, device='cuda')}
   torch.manual_seed(1 + rank)
-  for _ in range(max(1, args.warmup)):
+  for _ in range(max(1, warmup)):
     loss = tr.training_step(batch)
   torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
-  steps = args.steps if args.steps > 2 else 20
   t0 = time.perf_counter()
   for _ in range(steps):
     loss = tr.training_step(batch)
@@ -170,30 +260,98 @@ def train_bench(args):
   el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
   n_par = sum(p.numel() for p in model.backbone.parameters())
   # forward flops per token: blocks 2*(3+1+8)*D^2 + attention 4*L*D, vocab 2*D*V; x3 for fwd+bwd
-  D, nb = cfg.model.hidden_size, cfg.model.n_blocks
+  D, nb, H = cfg.model.hidden_size, cfg.model.n_blocks, cfg.model.n_heads
   f_tok = nb * (24 * D * D + 4 * L * D) + 2 * D * V
   out = {'metric': 'LM1B MDLM training step tokens/sec (DiT-small, L=128, global batch 512)',
          'value': round(world * B * L * steps / el, 1), 'unit': 'tokens/s', 'n_gpus': world,
-         'steps': steps, 'warmup': max(1, args.warmup), 'ms_per_step': round(el / steps * 1e3, 2),
+         'steps': steps, 'warmup': max(1, warmup), 'ms_per_step': round(el / steps * 1e3, 2),
          'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16',
          'data': 'synthetic',
          'config': {'workload': f'LM1B MDLM training step, DiT-small ({n_par/1e6:.1f}M), L={L}, '
                                 f'global batch {world * B}, V={V}, dropout 0.1, clip 1.0, AdamW+EMA',
                     'batch_per_gpu': B, 'parallelism': f'ddp x{world}',
                     'grad_allreduce_mbytes': round(tr.n_flat * 4 / 1e6, 1)},
-         'dist': dist_block(world, dev),
          'loss': round(float(loss), 4),
          'model_tflops': round(3 * f_tok * world * B * L * steps / el / 1e12, 1)}
+  if profile:
+    # one more step with HIP events around every kernel call (outside the timed region)
+    with OpTimer() as ot:
+      tr.training_step(batch)
+    # attention: forward 4 L^2 d per (sequence, head); backward 5 matmuls = 10 L^2 d
+    att = {'attn_fwd_lse': 4.0 * L * L * 64 * B * H, 'attn_bwd': 10.0 * L * L * 64 * B * H}
+    ks = ot.summary(att)
+    mf = [k for k in ks if k.get('bound') == 'mfma']
+    if mf:
+      out['roofline'] = dict(mf[0], kernel={'gemm_tn_splitk': 'gemm_tn_splitk_kernel (dW = dY^T X, token-major, + splitk_reduce)',
+                                            'gemm_bf16': 'gemm_bf16_kernel<STORE / QKV_ROTARY> (forward + dX GEMMs)',
+                                            'attn_bwd': 'attn_bwd_l128_kernel'}.get(mf[0]['op'], mf[0]['op']))
+    out['kernels'] = ks[:12]
+  del tr, model
+  torch.cuda.empty_cache()
+  return out
+
+
+def train_bench(args):
+  rank, local_rank, world = mdist.init()
+  torch.cuda.set_device(mdist.local_device(local_rank))
+  dev = torch.device('cuda', mdist.local_device(local_rank))
+  out = train_block(args.steps if args.steps > 2 else 20, args.warmup, args.global_batch,
+                    rank, world, dev)
+  out['dist'] = dist_block(world, dev)
   if rank == 0:
     print(json.dumps(out), flush=True)
   mdist.barrier()
 
 
-def semi_ar_bench(args):
+def semi_ar_block(model, cfg, T, steps, warmup, rank, world, dev, profile_stride=8):
   """BASELINE.json configs[3]: semi-autoregressive generation (README recipe:
   L=1024 windows, stride 512, 2 extra strides -> 2048 tokens per sequence,
-  dt = 1/1000), batch 64 per GPU, replicas sharded by sample (no collective).
-  A step = one restore_model_and_semi_ar_sample over one batch."""
+  dt = 1/1000), batch per GPU = loader.eval_batch_size, replicas sharded by sample
+  (no collective).  A step = one restore_model_and_semi_ar_sample over one batch."""
+  B, L = cfg.loader.eval_batch_size, cfg.model.length
+  stride, n_str = 512, 2
+  run = lambda ns=n_str: model.restore_model_and_semi_ar_sample(
+    stride_length=stride, num_strides=ns, dt=1 / T)
+  for _ in range(warmup):
+    run()
+  torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    nfe_steps, _, _ = run()
+  torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
+  el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+  n_tok = L + n_str * stride
+  out = {'metric': 'semi-AR generation sequences/sec (2048 tokens, stride 512, T=1000 per window)',
+         'value': round(world * B * steps / el, 4), 'unit': 'sequences/s', 'n_gpus': world,
+         'steps': steps, 'warmup': warmup, 'ms_per_step': round(el / steps * 1e3, 1),
+         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
+         'data': 'synthetic',
+         'config': {'workload': f'semi-AR sample_subs_guidance, DiT-small, window L={L}, stride {stride}, '
+                                f'num_strides {n_str} -> {n_tok} tokens, dt=1/{T}, batch={B}/GPU',
+                    'parallelism': f'replicas x{world}'},
+         'tokens_per_sec': round(world * B * n_tok * steps / el, 1),
+         'sec_per_sequence_at_this_batch': round(el / steps / B, 4),
+         'steps_with_change': int(nfe_steps)}
+  if profile_stride > 0:
+    # profiling pass over ONE window (num_strides = 0), outside the timed region
+    global D_MODEL
+    D_MODEL = cfg.model.hidden_size
+    traffic, _ = load_traffic()
+    bb = model.backbone
+    bb.profile_events = {}
+    model._profile = dict(stride=profile_stride, rows=[])
+    run(0)
+    torch.cuda.synchronize()
+    events = bb.profile_events
+    bb.profile_events, model._profile = None, None
+    rl = kernel_rooflines(events, traffic)
+    dom = max((d for t, d in rl.items() if d['bound'] != 'launch' and t not in ('gemm_out', 'gemm_fc2')),
+              key=lambda d: d['total_ms'])
+    out['roofline'] = dom
+  return out
+
+
+def semi_ar_bench(args):
   rank, local_rank, world = mdist.init()
   torch.cuda.set_device(mdist.local_device(local_rank))
   dev = torch.device('cuda', mdist.local_device(local_rank))
@@ -203,31 +361,9 @@ def semi_ar_bench(args):
                      'sampling.fast_math=true', f'trainer.devices={world}'])
   model = build_model(cfg, seed=1)
   model.seed_rng(mdist.rank_seed(cfg.seed, rank))
-  B, L = args.batch, cfg.model.length
-  run = lambda: model.restore_model_and_semi_ar_sample(
-    stride_length=cfg.sampling.stride_length, num_strides=cfg.sampling.num_strides,
-    dt=1 / args.T)
-  for _ in range(args.warmup):
-    run()
-  torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    nfe_steps, _, _ = run()
-  torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
-  el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
-  n_tok = L + cfg.sampling.num_strides * cfg.sampling.stride_length
-  out = {'metric': 'semi-AR generation sequences/sec (2048 tokens, stride 512, T=1000 per window)',
-         'value': round(world * B * args.steps / el, 4), 'unit': 'sequences/s', 'n_gpus': world,
-         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(el / args.steps * 1e3, 1),
-         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
-         'data': 'synthetic',
-         'config': {'workload': f'semi-AR sample_subs_guidance, DiT-small, window L={L}, stride 512, '
-                                f'num_strides 2 -> {n_tok} tokens, dt=1/{args.T}, batch={B}/GPU',
-                    'parallelism': f'replicas x{world}'},
-         'dist': dist_block(world, dev),
-         'tokens_per_sec': round(world * B * n_tok * args.steps / el, 1),
-         'sec_per_sequence_at_this_batch': round(el / args.steps / B, 4),
-         'steps_with_change': int(nfe_steps)}
+  out = semi_ar_block(model, cfg, args.T, args.steps, args.warmup, rank, world, dev,
+                      profile_stride=args.profile_stride)
+  out['dist'] = dist_block(world, dev)
   if rank == 0:
     print(json.dumps(out), flush=True)
   mdist.barrier()
@@ -402,6 +538,8 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-policy-compare', action='store_true')
   ap.add_argument('--no-eval', action='store_true')
+  ap.add_argument('--no-semi-ar', action='store_true')
+  ap.add_argument('--no-train', action='store_true')
   args = ap.parse_args()
   if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
     raise SystemExit(self_launch(args))
@@ -461,10 +599,8 @@ def main():
   # stream around every kernel of each k-th step, live row counts of every step
   rooflines, executed = {}, None
   if args.profile_stride > 0:
-    traffic = {}
-    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(tpath):   # HBM bytes per launch from separate rocprofv3 --pmc passes
-      traffic = json.load(open(tpath))
+    # HBM bytes per launch from separate rocprofv3 --pmc passes, if taken on these kernels
+    traffic, traffic_source = load_traffic()
     bb.profile_events = {}
     model._profile = dict(stride=args.profile_stride, rows=[])
     model.restore_model_and_sample(num_steps=args.T)
@@ -513,7 +649,7 @@ def main():
     dom = max((d for t, d in rooflines.items()
                if d['bound'] != 'launch' and t not in ('gemm_out', 'gemm_fc2')),
               key=lambda d: d['total_ms'])
-    out['roofline'] = dom
+    out['roofline'] = dict(dom, traffic_source=traffic_source)
     out['rooflines'] = sorted((d for t, d in rooflines.items() if t != 'gemm_gate_residual'),
                               key=lambda d: -d['total_ms'])
     out['profile'] = {'stride': args.profile_stride,
@@ -551,6 +687,11 @@ def main():
                    'unit': 'tokens/s', 'batch_per_gpu': eb, 'batches': n_eval,
                    'val_nll': round(res['val/nll'], 4)}
 
+  if not args.no_semi_ar and args.cache_policy == 'sample' and not args.set:
+    # BASELINE configs[3] on the same model and sampler state (already warm): one batch
+    out['semi_ar'] = semi_ar_block(model, cfg, args.T, 1, 0, rank, world, dev,
+                                   profile_stride=args.profile_stride)
+
   if rank == 0 and world == 1 and not args.no_policy_compare and args.cache_policy == 'sample':
     # the reference's literal all-or-nothing cache policy, for the record
     cfg.sampling.cache_policy = 'batch'
@@ -579,9 +720,13 @@ def main():
       'nfe_per_sample': round(int(model.last_nfe.item()) / B, 1)}
     cfg.sampling.lazy_unmask = False
 
+  del model
+  torch.cuda.empty_cache()
+  if not args.no_train:
+    # BASELINE configs[4]: 20 LM1B training steps (its own model: V = 30,522, L = 128)
+    out['train'] = train_block(20, 3, args.global_batch, rank, world, dev,
+                               profile=args.profile_stride > 0)
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
-    del model
-    torch.cuda.empty_cache()
     out['cpu_baseline'] = cpu_baseline(cfg, args.T)
   if rank == 0:
     print(json.dumps(out), flush=True)

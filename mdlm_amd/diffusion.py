@@ -658,6 +658,7 @@ class Diffusion(_Base):
     t_all = (t_host[:, None] * torch.ones(n_samples, dtype=self.dtype)[None]
              ).contiguous().to(dev)
     sampling_steps_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    prof = self._profile
     for _ in range(num_strides + 1):
       x, x_next = st['xa'], st['xb']
       x.fill_(self.mask_index)
@@ -665,11 +666,14 @@ class Diffusion(_Base):
         x[:, :-stride_length] = target
       st['changed'].fill_(1)   # p_x0_cache = None
       for i in range(num_steps + 1):
+        if prof is not None:
+          self.backbone.profile_sample = i % prof['stride'] == 0
         sigma = self.noise(t_all[i])[0] if self.time_conditioning else None
         self._fused_step(st, x, x_next, t_all[i], dt, sigma)
         # sampling_steps counts iterations whose x changed (977-980)
         sampling_steps_dev += (st['changed'].max() > 0).to(torch.int64)
         x, x_next = x_next, x
+      self.backbone.profile_sample = False
       self._refresh_cache(st, x)
       ops.subs_argmax(st['cache'], x, self.mask_index, out=x_next)
       x = x_next.clone()

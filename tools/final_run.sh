@@ -21,7 +21,7 @@ tail -1 $O/bench_train.log
 timeout -k 10 300 python -u bench.py --workload semi_ar --steps 1 --warmup 1 > $O/bench_semi_ar.log 2>&1 || { tail -20 $O/bench_semi_ar.log; exit 1; }
 tail -1 $O/bench_semi_ar.log
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sample -o sample -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-policy-compare --no-eval --profile-stride 0 --set sampling.stream_groups=1 > $O/prof_sample.log 2>&1 || { tail -20 $O/prof_sample.log; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sample -o sample -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-policy-compare --no-eval --no-semi-ar --no-train --profile-stride 0 --set sampling.stream_groups=1 > $O/prof_sample.log 2>&1 || { tail -20 $O/prof_sample.log; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -o train -- python3 $R/bench.py --workload train --steps 5 > $O/prof_train.log 2>&1 || { tail -20 $O/prof_train.log; exit 1; }
 # keep only the summaries (the raw traces are large)
 find $O -name "*kernel_trace.csv" -delete

@@ -6,7 +6,7 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/pmc
 rm -rf $O; mkdir -p $O
-ARGS="--steps 1 --warmup 0 --T 100 --no-eval --no-cpu-baseline --no-policy-compare --profile-stride 0 --set sampling.stream_groups=1"
+ARGS="--steps 1 --warmup 0 --T 100 --no-eval --no-cpu-baseline --no-policy-compare --profile-stride 0 --no-semi-ar --no-train --set sampling.stream_groups=1"
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -- python3 $R/bench.py $ARGS > $O/f.log 2>&1 || { tail -5 $O/f.log; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -- python3 $R/bench.py $ARGS > $O/w.log 2>&1 || { tail -5 $O/w.log; exit 1; }

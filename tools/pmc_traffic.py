@@ -37,6 +37,22 @@ def collect(d, counter):
   return acc
 
 
+def stamp():
+  """What the figures were measured on: hash of the kernel sources (bench.py
+  refuses to replay them on other sources), git head when the caller passes one
+  (the GPU box has no .git: tools/pmc_run.sh reads .git_head), date."""
+  import datetime
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, root)
+  import bench
+  head = None
+  hp = os.path.join(root, '.git_head')
+  if os.path.exists(hp):
+    head = open(hp).read().strip() or None
+  return {'_csrc_sha16': bench.csrc_sha16(), '_git_head': head,
+          '_date': datetime.datetime.now(datetime.timezone.utc).strftime('%Y-%m-%dT%H:%MZ')}
+
+
 def main():
   fd, wd, out = sys.argv[1:4]
   fe, wr = collect(fd, 'FETCH_SIZE'), collect(wd, 'WRITE_SIZE')
@@ -55,6 +71,8 @@ def main():
                        'average rows per launch (the vocabulary GEMM, the update and the row kernels run on the '
                        'masked rows: their per-launch row count is taken from the same run)')
   res['_rows_per_launch_profiled'] = 65536
+  res['_T'] = 100
+  res.update(stamp())
   # kernels that run on the masked rows only: their average row count in this run
   # follows from the vocabulary GEMM's written bytes (V bf16 logits + one float2
   # per 64-column group for every row)
