@@ -360,13 +360,8 @@ extern "C" int mdlm_attn_bwd(const void* q, const void* k, const void* vt, const
   hipStream_t s = (hipStream_t)stream;
   if (L == LQ) {
     constexpr int LDS = (3 * LQ * LDP + 64 * LDW + 2 * LQ * LDW) * 2 + 2 * LQ * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_l128_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      if (e != hipSuccess) { set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-      attr_done = true;
-    }
+    static bool attr_done[MAX_DEVICES] = {};
+    if (int rc = ensure_dynamic_lds(&attn_bwd_l128_kernel, LDS, attr_done, "attn_bwd")) return rc;
     attn_bwd_l128_kernel<<<(unsigned)((int64_t)n_seq * H), 512, LDS, s>>>(
       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (const bf16_t*)o, (const bf16_t*)dout, lse,
       (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, H);

@@ -13,6 +13,30 @@ namespace mdlm {
 
 void set_error(const char* fmt, ...);
 
+// Per-device launch state.  hipFuncSetAttribute (dynamic-LDS opt-in) acts on the
+// CURRENT device's copy of a kernel and a persistent grid is sized by THAT
+// device's CU count, so both are kept per device, not per process: a process
+// that drives several GPUs gets each one set up on its first launch there.
+constexpr int MAX_DEVICES = 64;
+int current_device();          // hipGetDevice; -1 (with the error string set) on failure
+int device_cus(int dev);       // CU count of device `dev` (multiple of 8 XCDs), cached
+
+// Opt `kernel` in to `bytes` of dynamic LDS on the current device, once per device.
+// `done` is the caller's per-device flag array (one static array per kernel).
+template <typename K>
+inline int ensure_dynamic_lds(K kernel, int bytes, bool (&done)[MAX_DEVICES], const char* who, int* dev_out = nullptr) {
+  const int dev = current_device();
+  if (dev < 0) return -1;
+  if (dev_out) *dev_out = dev;
+  if (!done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return (int)e; }
+    done[dev] = true;
+  }
+  return 0;
+}
+
 #define MDLM_CHECK_ARG(cond, ...)            \
   do {                                       \
     if (!(cond)) {                           \

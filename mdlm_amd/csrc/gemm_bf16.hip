@@ -23,109 +23,9 @@
 // v^T[b,h,d,l] store wants).
 // Block ids are remapped so that each XCD (private 4 MiB L2) walks groups of
 // M-tiles x all N-tiles: the A panels stay L2-resident while W streams.
-#include "common.h"
-#include <type_traits>
+#include "gemm_common.h"
 
 namespace mdlm {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BK = 64;
-constexpr int EPI_BIAS_GELU_SAVE = 4;   // internal: mdlm_gemm_bf16_gelu mode 0
-constexpr int EPI_MUL_GELU_GRAD = 5;    // internal: mdlm_gemm_bf16_gelu mode 1
-
-struct GemmArgs {
-  const bf16_t* A; int64_t lda;
-  const bf16_t* W; int64_t ldw;
-  // split-K (fp32 EPI_STORE only): split s reduces K columns [s*K, (s+1)*K) of
-  // A and W into C + s*c_split_stride (partial sums, added up by a second kernel)
-  int splits; int64_t c_split_stride;
-  // training-step GELU fusions (bf16 outputs, same ldc as C):
-  //   EPI_BIAS_GELU_SAVE : aux = second OUTPUT, receives acc + bias (the pre-activation)
-  //   EPI_MUL_GELU_GRAD  : aux = INPUT pre-activation; C = (acc) * gelu'(aux)
-  void* aux;
-  const float* bias;
-  void* C; int64_t ldc;
-  int64_t M; int N; int K;
-  const float* gate; const float* residual;
-  int64_t rows_per_mod; int n_mod; int64_t mod_ld;
-  const int32_t* out_sample_map;
-  const int32_t* out_row_map;
-  const float* rot_cos; const float* rot_sin; int n_heads;
-  const int32_t* m_rows_dev;
-  // EPI_STORE bf16 only: per (row, 64-column group) softmax partials (max, sum of
-  // exp(x - max)) of the bf16-rounded outputs, column lse_skip excluded
-  float2* lse_part; int lse_skip; int lse_ng;
-  int tiles_m, tiles_n;
-  int vec_ok;  // ldc / alignment allow 16-byte row stores
-  int dbg;     // MDLM_GEMM_ABLATION builds only (2: skip the epilogue, 4: drop the stores)
-  int whole_tiles;   // tile bit 4: never cut the tiles of a short last round in two
-};
-
-// Timing ablations exist only in builds with -DMDLM_GEMM_ABLATION (scratch/
-// experiments); the release library carries no such switch and no global state.
-#ifdef MDLM_GEMM_ABLATION
-#define GEMM_DBG(g) ((g).dbg)
-#else
-#define GEMM_DBG(g) 0
-#endif
-
-#define GLDS16(gptr, lptr) \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
-                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
-__device__ __forceinline__ float gelu_tanh(float x) {
-  // nn.GELU(approximate='tanh'), dit.py:227:
-  //   0.5 x (1 + tanh(y)) = x * sigmoid(2y),  y = sqrt(2/pi) (x + 0.044715 x^3)
-  // exp(-z) = exp2(-z log2 e); v_exp_f32 / v_rcp_f32 are 1-ulp hardware ops,
-  // far inside the bf16 output rounding.
-  const float z2 = -2.3022082f * x * (1.f + 0.044715f * x * x);  // -1.5957691*log2(e)
-  return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(z2));
-}
-
-// the same on a pair: five packed fp32 ops + 2 x (v_exp_f32, v_rcp_f32)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
-  const f32x2 k1 = {-2.3022082f * 0.044715f, -2.3022082f * 0.044715f};
-  const f32x2 k0 = {-2.3022082f, -2.3022082f};
-  const f32x2 one = {1.f, 1.f};
-  const f32x2 w = x * __builtin_elementwise_fma(x * x, k1, k0);
-  const f32x2 e = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
-  const f32x2 d = e + one;
-  const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-  return x * r;
-}
-
-// d/dx of gelu_tanh: 0.5 (1 + th) + 0.5 x (1 - th^2) sqrt(2/pi) (1 + 3*0.044715 x^2),
-// th = tanh(y) = 1 - 2 / (1 + exp(2y))
-__device__ __forceinline__ float gelu_tanh_grad_fast(float x) {
-  const float x2 = x * x;
-  const float y2l = 2.3022082f * x * (1.f + 0.044715f * x2);   // 2y * log2(e)
-  const float th = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(y2l));
-  return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * (0.7978845608f * (1.f + 0.134145f * x2));
-}
-
-__device__ __forceinline__ float bf16_round(float x) { return bf16_to_f32(f32_to_bf16(x)); }
-// round a pair to bf16 and back: one v_cvt_pk_bf16_f32 + shift + and
-__device__ __forceinline__ f32x2 bf16_round2(float a, float b) {
-  const unsigned u = pack_bf16x2(a, b);
-  return (f32x2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
-}
-
-// 16-byte row store of the epilogue.  bf16 outputs (q/k, MLP hidden, logits)
-// are written once and read by a later kernel: non-temporal stores keep them
-// from displacing the A/W panels in L2 (measured -7..-14 % per launch); the
-// fp32 residual stream is read-modify-written in place and stays plain.
-// dbg bit 4 (timing experiments only) drops the store.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <bool NT>
-__device__ __forceinline__ void store16(void* p, uint4 v, int dbg) {
-  if (dbg & 4) return;
-  const u32x4 vv = {v.x, v.y, v.z, v.w};
-  if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(p));
-  else *reinterpret_cast<u32x4*>(p) = vv;
-}
 
 // Per-lane column constants of one wave tile, fetched BEFORE the main loop so
 // their latency is hidden (interior wave tiles only; `ok` is wave-uniform).
@@ -797,21 +697,16 @@ template <int EPI, typename TC, int WM, int WN, int MT>
 static int launch_cfg(GemmArgs g, hipStream_t s) {
   constexpr int TBM = WM * MT * 16, TBN = WN * 64;
   constexpr int LDS = 2 * (TBM + TBN) * BK * 2;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, TC, WM, WN, MT>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static bool attr_done[MAX_DEVICES] = {};
+  int dev = 0;
+  if (int rc = ensure_dynamic_lds(&gemm_bf16_kernel<EPI, TC, WM, WN, MT>, LDS, attr_done, "gemm", &dev)) return rc;
   g.tiles_m = (int)(g.M / TBM);
   g.tiles_n = (g.N + TBN - 1) / TBN;
   int64_t grid = (((int64_t)g.tiles_m * g.tiles_n * (g.splits > 1 ? g.splits : 1) + 7) / 8) * 8;
   if (grid >= (1ll << 31)) { set_error("gemm: grid too large"); return -1; }
   // persistent launch: one workgroup per CU for the 128 KiB-LDS tile, two for
   // the 64 KiB one
-  int64_t resident = (LDS > 80 * 1024) ? 256 : 512;
+  int64_t resident = (LDS > 80 * 1024) ? device_cus(dev) : 2 * device_cus(dev);
 #ifdef MDLM_GEMM_ABLATION
   if (g.dbg & 8) resident /= 2;   // experiment: half of the CUs
 #endif
@@ -831,6 +726,10 @@ static int launch_gemm(const GemmArgs& g, hipStream_t s, int tile = 0) {
 
 }  // namespace mdlm
 
+namespace mdlm {
+int gemm_pp_dispatch(const GemmArgs& g, int epilogue, int dtype_c, hipStream_t s);   // gemm_pp.hip
+}
+
 using namespace mdlm;
 
 extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
@@ -845,7 +744,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
                               int lse_skip_col, int tile, void* stream) {
   if (M == 0) return 0;
   MDLM_CHECK_ARG(A && W && C, "gemm_bf16: null pointer");
-  MDLM_CHECK_ARG((tile & ~31) == 0, "gemm_bf16: tile must be 0 (auto), 1 (128x128), optionally | 16 (whole tiles only)");
+  MDLM_CHECK_ARG((tile & ~63) == 0, "gemm_bf16: tile must be 0 (auto), 1 (128x128), optionally | 16 (whole tiles only) | 32 (two-accumulator-set kernel where it applies)");
   MDLM_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_bf16: bad shape");
   MDLM_CHECK_ARG(M % 128 == 0, "gemm_bf16: M=%lld must be a multiple of 128", (long long)M);
   MDLM_CHECK_ARG(K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d", K, BK);
@@ -862,6 +761,7 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
   g.rot_cos = rot_cos; g.rot_sin = rot_sin; g.n_heads = n_heads; g.m_rows_dev = m_rows_dev;
   g.tiles_m = 0; g.tiles_n = 0; g.dbg = tile & 14;   // ablation builds only
   g.whole_tiles = (tile >> 4) & 1;
+  const bool try_pp = (tile & 32) != 0;
   tile &= 1;
   g.ldw = K; g.splits = 1; g.c_split_stride = 0; g.aux = nullptr;
   g.lse_part = reinterpret_cast<float2*>(lse_partials_out); g.lse_skip = lse_skip_col;
@@ -890,6 +790,10 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
                      "gemm_bf16: GATE_RESIDUAL needs N, ldc multiples of 4 and 16-byte aligned buffers");
       MDLM_CHECK_ARG(mod_ld % 4 == 0 && (g.n_mod == 1 || (mod_ld >= N && g.rows_per_mod % 64 == 0)),
                      "gemm_bf16: bad gate leading dimension / rows_per_mod %% 64 != 0");
+      if (try_pp) {
+        const int rc = gemm_pp_dispatch(g, epilogue, dtype_c, s);
+        if (rc != -2) return rc;
+      }
       return launch_gemm<MDLM_EPI_GATE_RESIDUAL, float>(g, s, tile);
     case MDLM_EPI_QKV_ROTARY:
       MDLM_CHECK_ARG(rot_cos && rot_sin && n_heads > 0 && N == 3 * n_heads * 64,

@@ -273,16 +273,12 @@ extern "C" int mdlm_gemm_tn_splitk(const void* dY, int64_t ldy, const void* X, i
   g.splits = splits; g.tiles_n = N / 256; g.tiles_k = K / 256;
   const int64_t total = (int64_t)g.tiles_n * g.tiles_k * splits;
   MDLM_CHECK_ARG(total < (1ll << 30), "gemm_tn_splitk: too many tiles");
-  int64_t grid = (total + 7) / 8 * 8;
-  if (grid > 256) grid = 256;
   constexpr int LDS = 2 * TN_STAGE;   // 128 KiB: one workgroup per CU
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_splitk_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) { set_error("gemm_tn_splitk: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static bool attr_done[MAX_DEVICES] = {};
+  int dev = 0;
+  if (int rc = ensure_dynamic_lds(&gemm_tn_splitk_kernel, LDS, attr_done, "gemm_tn_splitk", &dev)) return rc;
+  int64_t grid = (total + 7) / 8 * 8;
+  if (grid > device_cus(dev)) grid = device_cus(dev);
   gemm_tn_splitk_kernel<<<(unsigned)grid, 512, LDS, (hipStream_t)stream>>>(g);
   MDLM_LAUNCH_CHECK();
   return 0;

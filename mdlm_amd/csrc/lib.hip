@@ -9,6 +9,23 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+int current_device() {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { set_error("hipGetDevice: %s", hipGetErrorString(e)); return -1; }
+  if (dev < 0 || dev >= MAX_DEVICES) { set_error("device index %d outside 0..%d", dev, MAX_DEVICES - 1); return -1; }
+  return dev;
+}
+int device_cus(int dev) {
+  static int cus[MAX_DEVICES] = {};   // racing first calls store the same value
+  if (dev < 0 || dev >= MAX_DEVICES) return 256;
+  if (!cus[dev]) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
+    cus[dev] = v & ~7;   // the tile walks deal workgroups to 8 XCDs
+  }
+  return cus[dev];
+}
 }  // namespace mdlm
 
 extern "C" int mdlm_version(void) { return MDLM_VERSION; }
