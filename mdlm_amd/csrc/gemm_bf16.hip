@@ -783,6 +783,10 @@ extern "C" int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W,
       return launch_gemm<MDLM_EPI_STORE, bf16_t>(g, s, tile);
     case MDLM_EPI_BIAS_GELU:
       MDLM_CHECK_ARG(ldc >= N && dtype_c == MDLM_BF16, "gemm_bf16: BIAS_GELU writes bf16 with ldc >= N");
+      if (try_pp) {
+        const int rc = gemm_pp_dispatch(g, epilogue, dtype_c, s);
+        if (rc != -2) return rc;
+      }
       return launch_gemm<MDLM_EPI_BIAS_GELU, bf16_t>(g, s, tile);
     case MDLM_EPI_GATE_RESIDUAL:
       MDLM_CHECK_ARG(gate && residual && dtype_c == MDLM_F32, "gemm_bf16: GATE_RESIDUAL needs gate, residual and fp32 C");

@@ -31,7 +31,6 @@ constexpr int NSTAGE = 3;
 constexpr int LDS_BYTES = NSTAGE * STAGE + 16384;   // 144 KiB ring + column constants (gate, bias: N <= 2048)
 constexpr int A_CH = (TBM / 8) / NW;        // 2 DMA instructions (1 KiB each) per wave and slab
 constexpr int B_CH = (TBN / 8) / NW;        // 4
-constexpr int DMA_PER_SLAB = A_CH + B_CH;   // 6
 constexpr int GROUP_M = 1024 / TBM;         // M tiles per A-row group of the tile walk
 
 #define PP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -92,6 +91,9 @@ void gemm_pp_kernel(GemmArgs g) {
       lds_cc[(i >> 2) * 8 + 4 + (i & 3)] = g.bias ? g.bias[i] : 0.f;
     }
     __syncthreads();
+  } else {   // bf16 outputs: bias[N] as it stands
+    for (int i = tid; i < g.N; i += 512) lds_cc[i] = g.bias ? g.bias[i] : 0.f;
+    __syncthreads();
   }
 
   // ---- loader: the slab stream, two slabs ahead of the MFMAs -----------------------
@@ -101,7 +103,14 @@ void gemm_pp_kernel(GemmArgs g) {
   const int srow = lane >> 3;
   const int skc = ((lane & 7) ^ srow) * 8;
   const int a_voff = (int)(((int64_t)(wid * 8 + srow) * g.lda + skc) * 2);
-  const int b_voff = (int)(((int64_t)(wid * 8 + srow) * g.ldw + skc) * 2);
+  // bf16 outputs: LDS row (nu, i) of a wave's 64 W rows (nu = 16-row MFMA block, i = row in
+  // it) holds W row 32 (nu / 2) + 8 (i / 4) + 4 (nu % 2) + i % 4, so that after the MFMAs a
+  // lane's values of blocks 2p and 2p + 1 are 8 CONSECUTIVE output columns: one 16-byte store
+  constexpr bool BF16_OUT = sizeof(TC) == 2;
+  const int w_lds = wid * 8 + srow;   // LDS row inside the 64-row group this wave stages
+  const int w_row = BF16_OUT ? 32 * (w_lds >> 5) + 8 * ((w_lds & 15) >> 2) + 4 * ((w_lds >> 4) & 1) + (w_lds & 3)
+                             : w_lds;
+  const int b_voff = (int)(((int64_t)w_row * g.ldw + skc) * 2);
   const char* a_tile = nullptr;   // first row of the loader's tile in A / W (uniform)
   const char* b_tile = nullptr;
   auto set_src = [&](int tm_, int tn_) {
@@ -117,25 +126,12 @@ void gemm_pp_kernel(GemmArgs g) {
   auto stage_next = [&]() {
     char* const sb = smem + ls;
     const int64_t k0 = (int64_t)ktL * BK * 2;
-#ifdef PP_ROLE_TEST   // timing experiment: waves 0-3 issue all the DMA (and never store), waves 4-7 none
-    if (wid < 4) {
-      const int a_v2 = (int)(((int64_t)(wid * 8 + srow) * g.lda + skc) * 2);
-      const int b_v2 = (int)(((int64_t)(wid * 8 + srow) * g.ldw + skc) * 2);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        GLDS16(a_tile + (k0 + (int64_t)i * 32 * g.lda * 2) + a_v2, sb + (i * 4 + wid) * 1024);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        GLDS16(b_tile + (k0 + (int64_t)i * 32 * g.ldw * 2) + b_v2, sb + A_BYTES + (i * 4 + wid) * 1024);
-    }
-#else
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
       GLDS16(a_tile + (k0 + (int64_t)i * 64 * g.lda * 2) + a_voff, sb + (i * NW + wid) * 1024);
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
       GLDS16(b_tile + (k0 + (int64_t)i * 64 * g.ldw * 2) + b_voff, sb + A_BYTES + (i * NW + wid) * 1024);
-#endif
     ls = ls == (NSTAGE - 1) * STAGE ? 0 : ls + STAGE;
     if (jL >= 0 && ++ktL == KT) {
       int tmL, tnL;
@@ -161,9 +157,6 @@ void gemm_pp_kernel(GemmArgs g) {
   // (it cannot tell the DMA's LDS writes from the load), which would drain the slab ring at
   // every unit; the counted wait is ours (wait_unit).
   auto load_unit = [&](int64_t row0, int col0, int u) {
-#ifdef PP_NO_LOADS   // timing experiment
-    return;
-#endif
     const float* rp = g.residual + (row0 + u * 16 + fr) * g.ldc + col0 + fq * 4;
     asm volatile("global_load_dwordx4 %0, %4, off\n\t"
                  "global_load_dwordx4 %1, %4, off offset:64\n\t"
@@ -198,22 +191,41 @@ void gemm_pp_kernel(GemmArgs g) {
     }
   };
   auto store_rs = [&](int u) {
-#ifdef PP_NO_STORES   // timing experiment
-    return;
-#endif
-#ifdef PP_ROLE_TEST
-    if (wid < 4) return;
-#endif
-#ifdef PP_FULLLINE_TEST   // timing experiment only (wrong placement): every instruction writes whole 128-byte lines
-    float* cp = Cp + (d_row0 + u * 16 + (lane >> 3)) * g.ldc + d_col0 + (lane & 7) * 4;
-    const int64_t s1 = 32, s2 = 8 * g.ldc;
-#else
     float* cp = Cp + (d_row0 + u * 16 + fr) * g.ldc + d_col0 + fq * 4;
     const int64_t s1 = 16, s2 = 32;
-#endif
 #pragma unroll
     for (int n = 0; n < 4; ++n)
       store16<false>(cp + (n & 1) * s1 + (n >> 1) * s2, make_uint4(__float_as_uint(rs[n][0]), __float_as_uint(rs[n][1]), __float_as_uint(rs[n][2]), __float_as_uint(rs[n][3])), GEMM_DBG(g));
+  };
+
+  // bf16 outputs: unit U of set P = 16 rows x 64 columns; a lane's two 16-byte stores
+  // (8 consecutive columns each, see w_row): gelu_tanh(acc + bias) (dit.py:225-228)
+  auto bf16_unit = [&](auto p_c, auto u_c) {
+    constexpr int P = decltype(p_c)::value, U = decltype(u_c)::value;
+    const unsigned cc = (unsigned)(NSTAGE * STAGE) + (unsigned)(d_col0 + fq * 8) * 4u;
+    f32x4 b[4];
+    asm volatile("ds_read_b128 %0, %4\n\t"
+                 "ds_read_b128 %1, %4 offset:16\n\t"
+                 "ds_read_b128 %2, %4 offset:128\n\t"
+                 "ds_read_b128 %3, %4 offset:144\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(cc) : "memory");
+    bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (d_row0 + U * 16 + fr) * g.ldc + d_col0 + fq * 8;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      unsigned o[4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 a = acc[P][U][2 * pr + h];
+        const f32x4 bb = b[2 * pr + h];
+        f32x2 lo = {a[0] + bb[0], a[1] + bb[1]};
+        f32x2 hi = {a[2] + bb[2], a[3] + bb[3]};
+        if constexpr (EPI == MDLM_EPI_BIAS_GELU) { lo = gelu_tanh2(lo); hi = gelu_tanh2(hi); }
+        o[2 * h] = pack_bf16x2(lo.x, lo.y);
+        o[2 * h + 1] = pack_bf16x2(hi.x, hi.y);
+      }
+      store16<true>(cp + pr * 32, make_uint4(o[0], o[1], o[2], o[3]), GEMM_DBG(g));
+    }
   };
 
   int cs = 0;                          // LDS offset of the stage the MFMAs read
@@ -223,8 +235,9 @@ void gemm_pp_kernel(GemmArgs g) {
   auto slab = [&](auto s_c, auto kind_c, auto u_c) {
     constexpr int S = decltype(s_c)::value, KIND = decltype(kind_c)::value;
     constexpr int U = decltype(u_c)::value;
-    if constexpr (KIND == EPI_SLAB) load_unit(d_row0, d_col0, U);
+    if constexpr (KIND == EPI_SLAB && !BF16_OUT) load_unit(d_row0, d_col0, U);
     stage_next();                                        // slab + 2
+
     const char* At = smem + cs + a_base;
     const char* Bt = smem + cs + b_base;
     bf16x8 af[2][4], bfr[2][4];
@@ -252,17 +265,18 @@ void gemm_pp_kernel(GemmArgs g) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-#ifdef PP_ROLE_TEST
-    if (wid < 4) PP_WAIT_VM(12);
-#else
     // slab + 1 landed; slab + 2 (6) and, behind a unit slab, its 4 stores stay in flight
-    if (after_unit) PP_WAIT_VM(10); else PP_WAIT_VM(6);
-#endif
+    if constexpr (BF16_OUT) { if (after_unit) PP_WAIT_VM(8); else PP_WAIT_VM(6); }
+    else { if (after_unit) PP_WAIT_VM(10); else PP_WAIT_VM(6); }
     after_unit = KIND == EPI_SLAB;
     if constexpr (KIND == EPI_SLAB) {
       __builtin_amdgcn_sched_barrier(0);
-      compute_unit(std::integral_constant<int, 1 - S>{}, u_c);
-      store_rs(U);
+      if constexpr (BF16_OUT) {
+        bf16_unit(std::integral_constant<int, 1 - S>{}, u_c);
+      } else {
+        compute_unit(std::integral_constant<int, 1 - S>{}, u_c);
+        store_rs(U);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -308,11 +322,7 @@ void gemm_pp_kernel(GemmArgs g) {
 
   stage_next();
   stage_next();
-#ifdef PP_ROLE_TEST
-  PP_WAIT_VM(12);
-#else
   PP_WAIT_VM(6);                       // slab 0 landed (this wave's part), slab 1 in flight
-#endif
   __builtin_amdgcn_s_barrier();
 
   auto next_tile = [&]() -> bool {
@@ -335,6 +345,10 @@ void gemm_pp_kernel(GemmArgs g) {
   // ---- the last tile leaves (unit 0's residual is in flight already) ----------------
   if (!(GEMM_DBG(g) & 2)) {
     auto drain = [&](auto p_c) {
+      if constexpr (BF16_OUT) {
+        bf16_unit(p_c, I0{}); bf16_unit(p_c, I1{}); bf16_unit(p_c, I2{}); bf16_unit(p_c, I3{});
+        return;
+      }
       load_unit(d_row0, d_col0, 0); PP_WAIT_VM(0); compute_unit(p_c, I0{}); store_rs(0);
       load_unit(d_row0, d_col0, 1); PP_WAIT_VM(0); compute_unit(p_c, I1{}); store_rs(1);
       load_unit(d_row0, d_col0, 2); PP_WAIT_VM(0); compute_unit(p_c, I2{}); store_rs(2);
@@ -370,6 +384,9 @@ int gemm_pp_dispatch(const GemmArgs& g, int epilogue, int dtype_c, hipStream_t s
   if (epilogue == MDLM_EPI_GATE_RESIDUAL && dtype_c == MDLM_F32 && g.N % pp::TBN == 0 &&
       g.N <= 2048 && g.n_mod == 1 && g.K >= 8 * BK)
     return pp::launch_pp<MDLM_EPI_GATE_RESIDUAL, float>(g, s);
+  if (epilogue == MDLM_EPI_BIAS_GELU && dtype_c == MDLM_BF16 && g.N % pp::TBN == 0 && g.N <= 4096 &&
+      g.K >= 8 * BK)
+    return pp::launch_pp<MDLM_EPI_BIAS_GELU, bf16_t>(g, s);
   return -2;
 }
 

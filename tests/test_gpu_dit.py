@@ -431,6 +431,45 @@ def test_gemm_half_tile_tail_is_bit_identical(ops):
   assert _rel(res[0][0][:4096].cpu(), ref.cpu()) < 1e-2
 
 
+def test_gemm_two_accumulator_set_kernel_is_bit_identical(ops):
+  """`tile | 32`: the 128x256 kernel with two accumulator sets (csrc/gemm_pp.hip: the
+  finished tile leaves from registers in units inside the next tile's K loop, W rows
+  permuted in LDS for the bf16 outputs) keeps the K order per output row, so its results
+  must equal the 256x256 kernel's bit for bit: gate/residual (out-projection K = 768,
+  MLP-down K = 3072 with bias) and bias + GELU (models/dit.py:277-287, 225-228), with one,
+  two and three tiles per workgroup and a device-side row count below the launch bound."""
+  from mdlm_amd._lib import EPI_BIAS_GELU, EPI_GATE_RESIDUAL
+  torch.manual_seed(12)
+  L, D = 1024, 768
+  for n_max, n_live in ((2, 2), (16, 13), (24, 24)):
+    M = n_max * L
+    h = _bf(torch.randn(M, D)).cuda()
+    mh = _bf(torch.randn(M, 4 * D)).cuda()
+    x0 = torch.randn(M, D).cuda()
+    Wo = _bf(torch.randn(D, D) * 0.05).cuda()
+    W2 = _bf(torch.randn(D, 4 * D) * 0.03).cuda(); b2 = (torch.randn(D) * 0.1).cuda()
+    W1 = _bf(torch.randn(4 * D, D) * 0.05).cuda(); b1 = (torch.randn(4 * D) * 0.1).cuda()
+    mod = torch.randn(1, 6 * D).cuda()
+    live = torch.tensor([n_live * L], dtype=torch.int32).cuda()
+    res = []
+    for tile in (0, 32):
+      x = x0.clone()
+      ops.gemm_bf16(h, Wo, x, EPI_GATE_RESIDUAL, gate=mod[:, :D], residual=x, rows_per_mod=L,
+                    n_mod=1, mod_ld=6 * D, m_rows_dev=live, tile=tile)
+      ops.gemm_bf16(mh, W2, x, EPI_GATE_RESIDUAL, bias=b2, gate=mod[:, D:2 * D], residual=x,
+                    rows_per_mod=L, n_mod=1, mod_ld=6 * D, m_rows_dev=live, tile=tile)
+      act = torch.zeros(M, 4 * D, dtype=torch.bfloat16).cuda()
+      ops.gemm_bf16(h, W1, act, EPI_BIAS_GELU, bias=b1, m_rows_dev=live, tile=tile)
+      res.append((x, act))
+    assert torch.equal(res[0][0], res[1][0]), (n_max, n_live)
+    assert torch.equal(res[0][1], res[1][1]), (n_max, n_live)
+    assert torch.equal(res[1][0][n_live * L:], x0[n_live * L:])      # rows past the live count untouched
+    assert not res[1][1][n_live * L:].any()
+    y = x0[:2048] + mod[:, :D] * (h[:2048].float() @ Wo.float().T)
+    y = y + mod[:, D:2 * D] * (mh[:2048].float() @ W2.float().T + b2)
+    assert _rel(res[1][0][:2048].cpu(), y.cpu()) < 1e-2
+
+
 def test_gemm_sample_scatter_leaves_dead_rows_of_a_partly_live_tile_alone(ops):
   """STORE epilogue with out_sample_map and samples shorter than a tile (L = 128,
   256-row tiles): with 3 live samples the second tile is half dead, and its dead
