@@ -96,7 +96,14 @@ int mdlm_ddpm_cache_update(const void* p_x0, int64_t ld, int dtype,
  * as from mdlm_subs_row_lse.  fresh (B) int32, optional: samples flagged
  * non-zero have new logits -- their masked rows' lse is recomputed in-kernel
  * (and stored to lse) before the race, so no separate lse pass is needed.
- * Same sampling semantics as above. */
+ * Same sampling semantics as above.
+ * Precondition of fast_math != 0 from logits: the logits of masked rows are
+ *   finite or -inf.  A NaN logit makes every lse this library computes (in-kernel
+ *   `fresh` pass, mdlm_subs_row_lse, the vocabulary GEMM's epilogue) NaN, which
+ *   routes the row to the defining arithmetic (torch semantics: NaN wins); with a
+ *   CALLER-computed finite lse over a row that holds a NaN the approximate pass
+ *   drops the NaN column instead (its prefilter and column skip take maxima).
+ *   fast_math == 0 has no precondition. */
 int mdlm_subs_ddpm_update(const void* logits, int64_t ld, int dtype,
                           float* lse, const int32_t* fresh,
                           const int64_t* x, const float* t,

@@ -556,6 +556,19 @@ __global__ __launch_bounds__(NT) void ddpm_update_kernel(
 // nor tie, in either arithmetic, and skips both logarithms (4.5 full-rate VALU operations
 // instead of 2 quarter-rate + 8 full-rate ones).  A vector of 8 columns is evaluated in full
 // as soon as the largest of its 8 bounds passes the test.
+//
+// Vector skip (SRC 1, same bar; round 3).  The bound n_v never needs the random bits to be
+// large: g_v >= 1e-10 - ln(1 - 2^-24 + 1e-10) > 2^-24.1 for EVERY 24-bit uniform (in both
+// arithmetics: measured over all 2^24 of them, test_race_key_error_exhaustive), i.e.
+// k_v <= l_v log2(e) + 24.1 whatever is drawn.  A vector of 8 columns with
+//     max_v l_v log2(e) + 24.5 < bar - margin - 1
+// therefore fails the prefilter for every possible draw -- it would be skipped anyway -- and
+// its two Philox blocks are not generated at all: the kernel is bound by exactly those
+// integer multiplies (VALU issue 0.99), so every such vector is ~90 VALU operations saved
+// for one v_max3 chain.  It fires for columns with p_v < ~2^-35 (t - dt) / (dt g_mask):
+// almost never on a near-uniform output layer, for most of the vocabulary once the model's
+// distribution is peaked (a trained checkpoint's tail tokens).  Same token ids by
+// construction: only columns the prefilter would have dropped are dropped.
 struct FastRace {
   float best = -INFINITY, sec = -INFINITY; int idx = 0x7fffffff;
   __device__ __forceinline__ void put(float k, int i) {
@@ -659,10 +672,32 @@ __global__ __launch_bounds__(NT) void ddpm_update_fast_kernel(
     if (row_head(row, V) == 0) {
       const int nvec = V / EPV;
       const uint4* vp = reinterpret_cast<const uint4*>(row);
-      for (int i = threadIdx.x; i < nvec; i += NT) {
+      // The vector skip costs a v_max3 chain per vector, about what it saves when one
+      // vector in eight skips; a wave whose first 256 vectors skipped less than a quarter of
+      // the time stops testing (a speed heuristic only: tested or not, the same columns
+      // reach the race).
+      bool try_skip = SRC == 1 && c_bar > -INFINITY;
+      int it = 0, n_skipped = 0;
+      for (int i = threadIdx.x; i < nvec; i += NT, ++it) {
         float f[EPV];
         unpack<T>(vp[i], f);
         const int v0 = i * EPV;
+        if constexpr (SRC == 1) {
+          if (try_skip) {
+            // no draw can lift any of these columns to the bar: skip their random numbers too
+            // (a NaN logit drops out of the maximum: finite logits are this path's precondition,
+            // include/mdlm_hip.h; -inf c_bar, i.e. no usable bar, never skips)
+            float mx = f[0];
+#pragma unroll
+            for (int k = 1; k < EPV; ++k) mx = fmaxf(mx, f[k]);
+            const bool sk = __builtin_fmaf(mx, 1.4426950408889634f, 24.5f) < c_bar;
+            if (it < 4) {
+              n_skipped += __popcll(__ballot(sk));
+              if (it == 3) try_skip = n_skipped >= 64;
+            }
+            if (sk) continue;
+          }
+        }
         unsigned rb[EPV];
 #pragma unroll
         for (int gq = 0; gq < EPV / 4; ++gq) {
