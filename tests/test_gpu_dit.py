@@ -271,7 +271,10 @@ def _make_model(hidden, heads, blocks, cond, V, seed):
   return m.cuda(), p
 
 
-@pytest.mark.parametrize('shape', [(128, 2, 2, 64, 300, 128), (768, 12, 2, 128, 1000, 256), (128, 2, 1, 64, 700, 512)])
+@pytest.mark.parametrize('shape', [(128, 2, 2, 64, 300, 128), (768, 12, 2, 128, 1000, 256), (128, 2, 1, 64, 700, 512),
+                                   # the widths of the reference's other DiT configs (configs/model/medium.yaml:
+                                   # 1024 / 16 heads; tiny.yaml: 512 / 8 heads), two blocks each
+                                   (1024, 16, 2, 128, 1000, 256), (512, 8, 2, 128, 1000, 256)])
 def test_dit_forward_vs_oracle(ops, shape):
   hidden, heads, blocks, cond, V, L = shape
   model, p = _make_model(hidden, heads, blocks, cond, V, seed=3)
@@ -286,7 +289,9 @@ def test_dit_forward_vs_oracle(ops, shape):
     assert _rel(o, ref) < 2e-2, _rel(o, ref)
     # log-probs within the bf16 tolerance
     lp = torch.log_softmax(o, -1); lr = torch.log_softmax(ref, -1)
-    assert (lp - lr).abs().max().item() < 6e-2
+    # bf16 logits: the absolute error grows with the logit magnitude (|logit| up to 16 at the
+    # widest shape: one bf16 ulp there is 0.0625)
+    assert (lp - lr).abs().max().item() < (6e-2 if hidden <= 768 else 1e-1)
     assert (lp - lr).abs().mean().item() < 1e-2
   # empty batch: every kernel entry point is a no-op
   e = model(torch.zeros(0, L, dtype=torch.int64).cuda(), torch.zeros(0).cuda())
