@@ -2,7 +2,7 @@
 kernel, one library, one process, interleaved launches; bit-identity checked first.
   python3 scratch/ab_pp.py [lib.so] [n_samples ...]     (dbg bits via MODE env: 2 = no epilogue)"""
 import ctypes as C, os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mdlm_amd._lib import SIGNATURES, EPI_GATE_RESIDUAL
 path = sys.argv[1] if len(sys.argv) > 1 else 'mdlm_amd/libmdlm_hip.so'
 l = C.CDLL(os.path.abspath(path))

@@ -1,6 +1,6 @@
 """MLP-up (bias + GELU, bf16) : two-accumulator-set kernel (tile | 32) vs the 256x256 kernel."""
 import ctypes as C, os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mdlm_amd._lib import SIGNATURES, EPI_BIAS_GELU
 path = sys.argv[1] if len(sys.argv) > 1 else 'mdlm_amd/libmdlm_hip.so'
 l = C.CDLL(os.path.abspath(path))
