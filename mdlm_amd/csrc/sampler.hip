@@ -672,56 +672,64 @@ __global__ __launch_bounds__(NT) void ddpm_update_fast_kernel(
     if (row_head(row, V) == 0) {
       const int nvec = V / EPV;
       const uint4* vp = reinterpret_cast<const uint4*>(row);
-      // The vector skip costs a v_max3 chain per vector, about what it saves when one
-      // vector in eight skips; a wave whose first 256 vectors skipped less than a quarter of
-      // the time stops testing (a speed heuristic only: tested or not, the same columns
-      // reach the race).
-      bool try_skip = SRC == 1 && c_bar > -INFINITY;
-      int it = 0, n_skipped = 0;
-      for (int i = threadIdx.x; i < nvec; i += NT, ++it) {
-        float f[EPV];
-        unpack<T>(vp[i], f);
-        const int v0 = i * EPV;
-        if constexpr (SRC == 1) {
-          if (try_skip) {
+      // Vector skip: decided per WAVE from its lanes' first vectors (three quarters of the 64
+      // must be skippable), and the loop exists twice, so that waves that do not skip -- every
+      // wave on a near-uniform output layer -- run exactly the code without the test.  A speed
+      // heuristic only: tested or not, the same columns reach the race.
+      auto vec_loop = [&](auto skip_c, auto probe_c, int i0) -> bool {
+        constexpr bool SKIP = decltype(skip_c)::value, PROBE = decltype(probe_c)::value;
+        bool probe = false;
+        for (int i = i0; i < nvec; i += NT) {
+          float f[EPV];
+          unpack<T>(vp[i], f);
+          const int v0 = i * EPV;
+          if constexpr (SKIP || PROBE) {
             // no draw can lift any of these columns to the bar: skip their random numbers too
             // (a NaN logit drops out of the maximum: finite logits are this path's precondition,
-            // include/mdlm_hip.h; -inf c_bar, i.e. no usable bar, never skips)
+            // include/mdlm_hip.h)
             float mx = f[0];
 #pragma unroll
             for (int k = 1; k < EPV; ++k) mx = fmaxf(mx, f[k]);
             const bool sk = __builtin_fmaf(mx, 1.4426950408889634f, 24.5f) < c_bar;
-            if (it < 4) {
-              n_skipped += __popcll(__ballot(sk));
-              if (it == 3) try_skip = n_skipped >= 64;
+            if constexpr (PROBE) probe = sk;
+            else if (sk) continue;
+          }
+          unsigned rb[EPV];
+#pragma unroll
+          for (int gq = 0; gq < EPV / 4; ++gq) {
+            const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)((v0 >> 2) + gq));
+            rb[gq * 4 + 0] = rn.x; rb[gq * 4 + 1] = rn.y;
+            rb[gq * 4 + 2] = rn.z; rb[gq * 4 + 3] = rn.w;
+          }
+          bool go = true;
+          if constexpr (SRC == 1) {
+            float hi = key_bound(f[0], rb[0]);
+#pragma unroll
+            for (int k = 1; k < EPV; ++k) hi = fmaxf(hi, key_bound(f[k], rb[k]));
+            go = hi >= c_bar;
+          }
+          if (go) {
+            float key[EPV];
+#pragma unroll
+            for (int k = 0; k < EPV; ++k) key[k] = key_of(f[k], rb[k], v0 + k);
+#pragma unroll
+            for (int k = 0; k < EPV; ++k) {
+              fr.put(key[k], v0 + k);
+              if constexpr (SRC == 0) acc += key[k];
             }
-            if (sk) continue;
           }
+          if constexpr (PROBE) break;   // the first vector only
         }
-        unsigned rb[EPV];
-#pragma unroll
-        for (int gq = 0; gq < EPV / 4; ++gq) {
-          const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)((v0 >> 2) + gq));
-          rb[gq * 4 + 0] = rn.x; rb[gq * 4 + 1] = rn.y;
-          rb[gq * 4 + 2] = rn.z; rb[gq * 4 + 3] = rn.w;
-        }
-        bool go = true;
-        if constexpr (SRC == 1) {
-          float hi = key_bound(f[0], rb[0]);
-#pragma unroll
-          for (int k = 1; k < EPV; ++k) hi = fmaxf(hi, key_bound(f[k], rb[k]));
-          go = hi >= c_bar;
-        }
-        if (go) {
-          float key[EPV];
-#pragma unroll
-          for (int k = 0; k < EPV; ++k) key[k] = key_of(f[k], rb[k], v0 + k);
-#pragma unroll
-          for (int k = 0; k < EPV; ++k) {
-            fr.put(key[k], v0 + k);
-            if constexpr (SRC == 0) acc += key[k];
-          }
-        }
+        return probe;
+      };
+      if constexpr (SRC == 1) {
+        // first vector of every lane: evaluated in full AND probed for skippability
+        const bool sk0 = vec_loop(std::false_type{}, std::true_type{}, threadIdx.x);
+        const bool wave_skips = c_bar > -INFINITY && __popcll(__ballot(sk0)) >= 48;
+        if (wave_skips) vec_loop(std::true_type{}, std::false_type{}, threadIdx.x + NT);
+        else vec_loop(std::false_type{}, std::false_type{}, threadIdx.x + NT);
+      } else {
+        vec_loop(std::false_type{}, std::false_type{}, threadIdx.x);
       }
       for (int v = nvec * EPV + threadIdx.x; v < V; v += NT) {
         const uint4 rn = Philox::gen(seed, ctr0 + (uint64_t)(v >> 2));
