@@ -179,7 +179,8 @@ def test_stream_groups_are_result_identical(ops):
   """`sampling.stream_groups` runs the backbone forwards of disjoint sample
   ranges on separate HIP streams (per-group active lists, row lists and
   workspaces, joined before the update kernel): same tokens, same NFE, also in
-  the semi-AR driver that shares the cache refresh."""
+  the semi-AR driver that shares the cache refresh (same count of steps in which
+  a token changed)."""
   outs = []
   for g in (1, 2, 4):
     model, cfg, _ = make_model([f'sampling.stream_groups={g}', 'loader.eval_batch_size=8'])
@@ -188,11 +189,12 @@ def test_stream_groups_are_result_identical(ops):
     nfe = int(model.last_nfe.item())
     assert len(model._state['groups']) == g
     model.seed_rng(12)
-    _, inter, _ = model.sample_subs_guidance(n_samples=8, stride_length=64, num_strides=1, dt=1 / 16)
-    outs.append((x, nfe, inter))
+    n_chg, inter, _ = model.sample_subs_guidance(n_samples=8, stride_length=64, num_strides=1, dt=1 / 16)
+    outs.append((x, nfe, inter, n_chg))
   for o in outs[1:]:
     assert torch.equal(outs[0][0], o[0]) and outs[0][1] == o[1]
-    assert outs[0][2] == o[2]
+    assert outs[0][2] == o[2] and outs[0][3] == o[3]
+  assert 2 < outs[0][3] <= 2 * 17
   assert (outs[0][0] != MASK).all()
   # the other cache-refresh variants under two groups: every row projected; row lse in the update kernel
   for ov in ('sampling.masked_rows_only=false', 'sampling.lse_from_gemm=false'):
