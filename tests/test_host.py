@@ -1,6 +1,7 @@
 """CPU-only tests: host logic, configuration, the C-ABI surface (load + symbol
 export, no compute), loud failure without a GPU, and the N>1 sharding /
 all-reduce path over gloo (world_size 2)."""
+import json
 import math
 import os
 import re
@@ -203,6 +204,76 @@ def test_ema_swap_roundtrip():
   assert torch.allclose(w, orig + 1)
   model._ema_swap_out()
   assert torch.equal(w.detach(), orig)
+
+
+def test_shadow_weights_layout_checkpoint_and_guards():
+  """`ShadowWeights` (stands where models/ema.py's object stands): the checkpoint
+  layout of models/ema.py:89-97 in `parameters()` order, 256-byte aligned views of
+  one flat buffer, an exchange that needs no third copy, and the guards."""
+  from mdlm_amd.shadow import ALIGN, ShadowWeights, flat_layout
+  table, n = flat_layout([(3, 5), (7,), (64,), ()])
+  assert [t[0] for t in table] == [0, 64, 128, 192] and n == 256 and ALIGN == 64
+  assert [t[1] for t in table] == [15, 7, 64, 1]
+  ps = [torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7)),
+        torch.nn.Parameter(torch.randn(2), requires_grad=False)]
+  sh = ShadowWeights(ps, decay=0.9999)
+  assert len(sh.table) == 2 and sh.flat.numel() == 128      # frozen parameters have no shadow
+  assert all(torch.equal(v, p) for v, p in zip(sh.shadow_params, ps))
+  assert sh.shadow_params[1].data_ptr() - sh.flat.data_ptr() == 256
+  sd = sh.state_dict()
+  assert list(sd) == ['decay', 'num_updates', 'shadow_params'] and sd['num_updates'] == 0
+  assert [tuple(t.shape) for t in sd['shadow_params']] == [(3, 5), (7,)]
+  # round trip through the reference layout
+  sd2 = {'decay': 0.5, 'num_updates': 41, 'shadow_params': [t + 2 for t in sd['shadow_params']]}
+  sh.load_state_dict(sd2)
+  assert sh.decay == 0.5 and sh.num_updates == 41
+  assert torch.equal(sh.shadow_params[0], ps[0].detach() + 2)
+  # exchange: live <-> averaged, and back
+  live = [p.detach().clone() for p in ps]
+  sh.swap_in(ps)
+  assert torch.equal(ps[0].detach(), live[0] + 2) and torch.equal(ps[2], live[2])
+  assert torch.equal(sh.views()[0], live[0])                # the live values wait in the buffer
+  for call in (sh.state_dict, lambda: sh.shadow_params, lambda: sh.load_state_dict(sd2),
+               lambda: sh.swap_in(ps)):
+    with pytest.raises(RuntimeError, match='swapped in'):
+      call()
+  sh.swap_out(ps)
+  assert all(torch.equal(p.detach(), l) for p, l in zip(ps, live))
+  assert torch.equal(sh.shadow_params[0], live[0] + 2)
+  with pytest.raises(RuntimeError, match='without swap_in'):
+    sh.swap_out(ps)
+  with pytest.raises(ValueError, match='outside'):
+    ShadowWeights(ps, decay=1.5)
+  with pytest.raises(ValueError, match='shadow tensors for'):
+    sh.assign([torch.zeros(3, 5)])
+  with pytest.raises(ValueError, match='of shape'):
+    sh.assign([torch.zeros(3, 5), torch.zeros(8)])
+  assert bool(ShadowWeights([], decay=0.5)) is True          # truthiness is not "has parameters"
+
+
+def test_bench_replays_pmc_traffic_only_for_the_kernels_it_was_measured_on(tmp_path, monkeypatch):
+  """bench.py's `roofline.traffic` comes from committed PMC passes; the file is
+  stamped with a hash of the kernel sources and dropped when they changed."""
+  sys.path.insert(0, ROOT)
+  import bench
+  assert len(bench.csrc_sha16()) == 16 and bench.csrc_sha16() == bench.csrc_sha16()
+  prof = tmp_path / 'profiles'
+  prof.mkdir()
+  monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+  t, src = bench.load_traffic()
+  assert t == {} and src['used'] is False and src['file'] is None
+  monkeypatch.setattr(bench, 'csrc_sha16', lambda: 'a' * 16)
+  body = {'_csrc_sha16': 'a' * 16, '_git_head': 'deadbeef', '_date': 'd', '_T': 100,
+          'gemm_fc1': {'hbm_bytes_per_launch': 5}}
+  (prof / 'pmc_traffic.json').write_text(json.dumps(body))
+  t, src = bench.load_traffic()
+  assert t['gemm_fc1']['hbm_bytes_per_launch'] == 5 and src['used'] is True and src['git_head'] == 'deadbeef'
+  monkeypatch.setattr(bench, 'csrc_sha16', lambda: 'b' * 16)
+  t, src = bench.load_traffic()
+  assert t == {} and src['used'] is False and 'changed' in src['why']
+  # the committed file carries a stamp (whether it matches this tree is the bench's business)
+  committed = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+  assert len(committed['_csrc_sha16']) == 16 and committed['_T'] == 100
 
 
 def test_state_dict_layout_matches_reference():
