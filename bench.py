@@ -550,6 +550,21 @@ def kernel_rooflines(events, traffic):
   return out
 
 
+def start_heartbeat(period_s=30.0):
+  """A line on STDERR every `period_s` seconds for as long as the process lives, so that
+  a harness that takes a silent process for a hung one sees the long timed region
+  (minutes of asynchronous launches, no output by design) as alive.  A daemon thread
+  that only sleeps and writes: it touches neither the GPU nor the timed loop."""
+  import threading
+  t0 = time.time()
+
+  def beat():
+    while True:
+      time.sleep(period_s)
+      print(f'[bench] running, {time.time() - t0:.0f} s', file=sys.stderr, flush=True)
+  threading.Thread(target=beat, daemon=True).start()
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--workload', default='sample',
@@ -579,6 +594,8 @@ def main():
   if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
     raise SystemExit(self_launch(args))
   world_env = int(os.environ.get('WORLD_SIZE', 1))
+  if int(os.environ.get('RANK', 0)) == 0:
+    start_heartbeat()
   # a stuck rank dumps its Python stacks and exits non-zero (always armed for N > 1)
   dump_s = os.environ.get('MDLM_FAULT_DUMP_S') or ('1500' if world_env > 1 else '')
   if dump_s:
