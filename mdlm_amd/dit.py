@@ -114,6 +114,8 @@ class DIT(nn.Module):
     self.profile_events = None   # bench.py profiling pass only (see _timed)
     self.profile_sample = False
     self._ws = None     # activation workspace
+    # block GEMM launches of at most this many 256x256 tiles use 128x128 tiles (run)
+    self.small_tile_limit = 128
     self._ws_groups = {}
 
   # ------------------------------------------------------------ preparation
@@ -303,7 +305,17 @@ class DIT(nn.Module):
         ws['lsep_key'] = (M, V)
       lsep = ws['lsep']
     n_blocks = len(p['blocks'])
-    gt = (ops.DEFAULT_GEMM_TILE | 16) if concurrent else None
+
+    def gemm_tile(N, whole=False):
+      """`tile` of a block GEMM with N output columns.  A launch of only a few samples
+      (up to `small_tile_limit` 256x256 tiles, half of the CUs) runs on the 128x128
+      configuration: four times the workgroups, 0.5-0.7x the time at 1-8 samples
+      (scratch/small_tiles.py), and the same K order per output element, so the results
+      are bit-identical whatever the launch size (tests/test_gpu_dit.py)."""
+      t = ops.DEFAULT_GEMM_TILE
+      if M % 256 == 0 and (M // 256) * ((N + 255) // 256) <= self.small_tile_limit:
+        t |= 1
+      return (t | 16) if (concurrent and whole) else t
     for bi, (bp, mod) in enumerate(zip(p['blocks'], mods)):
       # chunk order dit.py:249-250: shift_msa, scale_msa, gate_msa, shift_mlp,
       # scale_mlp, gate_mlp
@@ -311,7 +323,7 @@ class DIT(nn.Module):
         x, bp['n1'], mod[:, 0:D], mod[:, D:2 * D], h, L, n_mod, ld6, n_rows_dev))
       T('gemm_qkv', rows_t, GEMM * 3 * D, lambda: ops.gemm_bf16(
         h, bp['qkv'], qkv, EPI_QKV_ROTARY, rows_per_mod=L, rot_cos=p['cos'],
-        rot_sin=p['sin'], n_heads=H, m_rows_dev=n_rows_dev, ldc=0, M=M, tile=gt))
+        rot_sin=p['sin'], n_heads=H, m_rows_dev=n_rows_dev, ldc=0, M=M, tile=gemm_tile(3 * D, True)))
       T('attention', rows_t, 4.0 * L * D, lambda: ops.attn_fwd(
         q_, k_, vt_, ao, n_seq, H, L, n_seq_dev=n_active_dev))
       if tail_rows and bi == n_blocks - 1:
@@ -322,15 +334,15 @@ class DIT(nn.Module):
           x, xm, ao, aom, gather, n_rows_dev=live, rows=M))
         T('gemm_out', lt, GEMM * D, lambda: ops.gemm_bf16(
           aom, bp['out'], xm, EPI_GATE_RESIDUAL, gate=mod[:, 2 * D:3 * D],
-          residual=xm, rows_per_mod=L, n_mod=1, mod_ld=ld6, m_rows_dev=live, M=M, tile=gt))
+          residual=xm, rows_per_mod=L, n_mod=1, mod_ld=ld6, m_rows_dev=live, M=M, tile=gemm_tile(D, True)))
         T('ln_modulate', lt, LN_B, lambda: ops.ln_modulate(
           xm, bp['n2'], mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D], h, L, 1, ld6, live))
         T('gemm_fc1', lt, GEMM * 4 * D, lambda: ops.gemm_bf16(
-          h, bp['fc1'], mh, EPI_BIAS_GELU, bias=bp['b1'], m_rows_dev=live, M=M))
+          h, bp['fc1'], mh, EPI_BIAS_GELU, bias=bp['b1'], m_rows_dev=live, M=M, tile=gemm_tile(4 * D)))
         T('gemm_fc2', lt, GEMM * 4 * D, lambda: ops.gemm_bf16(
           mh, bp['fc2'], xm, EPI_GATE_RESIDUAL, bias=bp['b2'],
           gate=mod[:, 5 * D:6 * D], residual=xm, rows_per_mod=L, n_mod=1,
-          mod_ld=ld6, m_rows_dev=live, M=M, tile=gt))
+          mod_ld=ld6, m_rows_dev=live, M=M, tile=gemm_tile(D, True)))
         fm = mods[-1]
         T('ln_modulate', lt, LN_B, lambda: ops.ln_modulate(
           xm, p['final']['n'], fm[:, 0:D], fm[:, D:2 * D], h, L, 1, ld2, live))
@@ -345,16 +357,16 @@ class DIT(nn.Module):
       T('gemm_out', rows_t, GEMM * D, lambda: ops.gemm_bf16(
         ao, bp['out'], x, EPI_GATE_RESIDUAL, gate=mod[:, 2 * D:3 * D],
         residual=x, rows_per_mod=L, n_mod=n_mod, mod_ld=ld6,
-        m_rows_dev=n_rows_dev, M=M, tile=gt))
+        m_rows_dev=n_rows_dev, M=M, tile=gemm_tile(D, True)))
       T('ln_modulate', rows_t, LN_B, lambda: ops.ln_modulate(
         x, bp['n2'], mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D], h, L, n_mod, ld6,
         n_rows_dev))
       T('gemm_fc1', rows_t, GEMM * 4 * D, lambda: ops.gemm_bf16(
-        h, bp['fc1'], mh, EPI_BIAS_GELU, bias=bp['b1'], m_rows_dev=n_rows_dev, M=M))
+        h, bp['fc1'], mh, EPI_BIAS_GELU, bias=bp['b1'], m_rows_dev=n_rows_dev, M=M, tile=gemm_tile(4 * D)))
       T('gemm_fc2', rows_t, GEMM * 4 * D, lambda: ops.gemm_bf16(
         mh, bp['fc2'], x, EPI_GATE_RESIDUAL, bias=bp['b2'],
         gate=mod[:, 5 * D:6 * D], residual=x, rows_per_mod=L,
-        n_mod=n_mod, mod_ld=ld6, m_rows_dev=n_rows_dev, M=M, tile=gt))
+        n_mod=n_mod, mod_ld=ld6, m_rows_dev=n_rows_dev, M=M, tile=gemm_tile(D, True)))
     if hidden_out is not None:
       ops.scatter_rows_f32(x, hidden_out, active, L, n_rows_dev=n_rows_dev)
       return None

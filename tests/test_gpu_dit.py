@@ -283,16 +283,24 @@ def test_dit_forward_vs_oracle(ops, shape):
   idx = torch.randint(0, V, (B, L))
   for sigma in (torch.zeros(B), torch.tensor([0.4, 1.7])):
     ref = orc.dit_forward(p, idx, sigma, heads, blocks)
-    out = model(idx.cuda(), sigma.cuda())
-    assert out.shape == (B, L, V) and out.dtype == torch.bfloat16
-    o = out.float().cpu()
-    assert _rel(o, ref) < 2e-2, _rel(o, ref)
-    # log-probs within the bf16 tolerance
-    lp = torch.log_softmax(o, -1); lr = torch.log_softmax(ref, -1)
-    # bf16 logits: the absolute error grows with the logit magnitude (|logit| up to 16 at the
-    # widest shape: one bf16 ulp there is 0.0625)
-    assert (lp - lr).abs().max().item() < (6e-2 if hidden <= 768 else 1e-1)
-    assert (lp - lr).abs().mean().item() < 1e-2
+    # DIT.run picks 128x128 GEMM tiles for launches of a few samples and 256x256 tiles
+    # otherwise (small_tile_limit): both against the oracle, and bit-identical to each other
+    outs = []
+    for lim in (0, 1 << 30):
+      model.small_tile_limit = lim
+      out = model(idx.cuda(), sigma.cuda())
+      assert out.shape == (B, L, V) and out.dtype == torch.bfloat16
+      o = out.float().cpu()
+      assert _rel(o, ref) < 2e-2, _rel(o, ref)
+      # log-probs within the bf16 tolerance
+      lp = torch.log_softmax(o, -1); lr = torch.log_softmax(ref, -1)
+      # bf16 logits: the absolute error grows with the logit magnitude (|logit| up to 16 at the
+      # widest shape: one bf16 ulp there is 0.0625)
+      assert (lp - lr).abs().max().item() < (6e-2 if hidden <= 768 else 1e-1)
+      assert (lp - lr).abs().mean().item() < 1e-2
+      outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1])
+    model.small_tile_limit = 128
   # empty batch: every kernel entry point is a no-op
   e = model(torch.zeros(0, L, dtype=torch.int64).cuda(), torch.zeros(0).cuda())
   assert e.shape == (0, L, V)
