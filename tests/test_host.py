@@ -276,6 +276,30 @@ def test_bench_replays_pmc_traffic_only_for_the_kernels_it_was_measured_on(tmp_p
   assert len(committed['_csrc_sha16']) == 16 and committed['_T'] == 100
 
 
+def test_bench_block_guard_keeps_the_headline():
+  """bench.py's secondary blocks (eval, semi_ar, train, ...) cannot cost the headline:
+  an exception becomes the block's error entry; a block that never returns makes the
+  process print the line as it stands and exit 0."""
+  sys.path.insert(0, ROOT)
+  import bench
+  out = {'value': 1.0}
+  g = bench.BlockGuard(out, 0)
+  g.run('ok', 5, lambda: out.__setitem__('ok', 1))
+  g.run('bad', 5, lambda: 1 / 0)
+  assert out['ok'] == 1 and 'ZeroDivisionError' in out['bad']['error'] and out['value'] == 1.0
+  code = ('import sys, time; sys.path.insert(0, %r); import bench; out = {"value": 2.5}; '
+          'bench.BlockGuard(out, 0).run("stuck", 1, lambda: time.sleep(120)); print("not reached")' % ROOT)
+  r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=200)
+  assert r.returncode == 0, r.stderr[-500:]
+  lines = r.stdout.strip().splitlines()
+  d = json.loads(lines[-1])
+  assert d['value'] == 2.5 and 'no result after 1 s' in d['stuck']['error'] and 'not reached' not in r.stdout
+  # the other ranks leave too, silently
+  r = subprocess.run([sys.executable, '-c', code.replace('BlockGuard(out, 0)', 'BlockGuard(out, 3)')],
+                     capture_output=True, text=True, timeout=200)
+  assert r.returncode == 0 and r.stdout.strip() == ''
+
+
 def test_state_dict_layout_matches_reference():
   """131 entries for DiT-small; same names as models/dit.py."""
   from mdlm_amd.dit import DIT
