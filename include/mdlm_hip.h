@@ -294,7 +294,14 @@ int mdlm_ln_modulate(const float* x, const float* ln_w, const float* shift,
  * any shape; the library holds no tuning state.  | 16: keep whole tiles in a short
  * last round (default: such tiles are cut into two half tiles of 128 rows, which
  * finishes a lone launch sooner but costs more CU time -- callers that overlap
- * launches on several streams pass 16).  Results do not depend on either. */
+ * launches on several streams pass 16).  | 32: the two-accumulator-set kernel
+ * (128x256 tiles, the finished tile leaves from registers inside the next tile's
+ * K loop) where it applies -- gate/residual fp32 with N % 256 == 0, N <= 2048, one
+ * gate row, and bias + GELU with N <= 4096, K >= 512 -- else the default kernel;
+ * measured not faster, kept opt-in.  Results do not depend on any of
+ * these bits: every configuration runs the same K order per output element, so a
+ * caller may pick the tile by launch size (mdlm_amd.dit.DIT.run gives launches of
+ * a few samples the 128x128 tiles). */
 int mdlm_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
                    void* C, int64_t ldc, int dtype_c, int64_t M, int N, int K,
                    int epilogue, const float* gate, const float* residual,
